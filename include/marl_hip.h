@@ -1,0 +1,185 @@
+/*
+ * marl_hip.h - C ABI of libmarl_hip.so: the MI355X (gfx950) implementation of
+ * MARLClassification's hot path (multi-agent episode rollout + A2C update).
+ *
+ * The reference (Ipsedo/MARLClassification) has no FFI: its hot path is Python
+ * over torch tensors.  Each entry point below therefore names the reference
+ * function(s) it replaces (paths relative to /root/reference/marl_classification).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *     fp32 tensors are contiguous, int64 where the reference uses int64;
+ *   - rows are r = a * nb + b, i.e. [Na, Nb, ...] tensors flattened over their
+ *     first two dimensions (networks/models.py:93);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on it, nothing synchronises the device;
+ *   - no hidden device allocations: the caller owns every buffer, including the
+ *     two workspaces whose sizes marl_workspace_sizes() reports.  Both must be
+ *     ZERO-FILLED once by the caller before first use (padding columns inside
+ *     them are never written and are read as zeros by the matrix kernels);
+ *   - return value: 0 on success, a negative MARL_E* code otherwise; nothing
+ *     throws across the ABI.  marl_last_error() gives a thread-local message.
+ */
+#ifndef MARL_HIP_H
+#define MARL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MARL_ABI_VERSION 1
+
+#define MARL_OK 0
+#define MARL_EINVAL (-1)   /* bad configuration / null pointer          */
+#define MARL_ELIMIT (-2)   /* dimension outside the supported range     */
+#define MARL_EHIP (-3)     /* a HIP runtime call failed                 */
+#define MARL_ESIZE (-4)    /* workspace too small                       */
+
+#define MARL_MAX_CNN_LAYERS 5
+#define MARL_MAX_ACTIONS 16
+
+/* Shape of one ModelsWrapper + Environment + EpisodeSampler triple
+ * (networks/models.py:37-50, core/environment.py:14-16, core/episode.py:24-30). */
+typedef struct marl_config {
+    int32_t nb_agents;   /* Na */
+    int32_t batch;       /* Nb */
+    int32_t nb_steps;    /* Ns */
+    int32_t img_c, img_h, img_w;  /* image batch [Nb, img_c, img_h, img_w] fp32 */
+    int32_t window;      /* f */
+    int32_t cnn_layers;  /* number of Conv-GroupNorm-SiLU blocks (vision.py:23-52) */
+    int32_t cnn_ch[MARL_MAX_CNN_LAYERS + 1]; /* cnn_ch[0] = channels the CNN reads
+                            (1 for MnistCnn: channel 0 only, vision.py:63-65), then
+                            the output channels of every layer */
+    int32_t cnn_groups[MARL_MAX_CNN_LAYERS];
+    int32_t n_b, n_a, n_m, n_m_o, n_d; /* belief / action / message / decoded / pos */
+    int32_t nb_action, nb_class;
+    int32_t nlb, nla;    /* hidden_size_belief / hidden_size_action of the heads */
+    int32_t actions[MARL_MAX_ACTIONS][2]; /* movement per action index (dim 0 = H) */
+} marl_config;
+
+/* Parameter table: an array of MARL_NPARAMS device pointers in this order.
+ * Shapes are those of the reference's state_dict() (tight, row-major):
+ *   4*l+0 conv_l.weight [co,ci,3,3]  4*l+1 conv_l.bias [co]
+ *   4*l+2 gn_l.weight [co]           4*l+3 gn_l.bias [co]          (l < 5, unused = NULL)
+ * then the indices below. */
+enum {
+    MARL_P_POS_W = 20, MARL_P_POS_B, MARL_P_POS_LNW, MARL_P_POS_LNB,          /* map_pos   */
+    MARL_P_ENC_W0, MARL_P_ENC_B0, MARL_P_ENC_LN0W, MARL_P_ENC_LN0B,
+    MARL_P_ENC_W1, MARL_P_ENC_B1, MARL_P_ENC_LN1W, MARL_P_ENC_LN1B,          /* encode_msg */
+    MARL_P_DEC_W0, MARL_P_DEC_B0, MARL_P_DEC_LN0W, MARL_P_DEC_LN0B,
+    MARL_P_DEC_W1, MARL_P_DEC_B1, MARL_P_DEC_LN1W, MARL_P_DEC_LN1B,          /* decode_msg */
+    MARL_P_LB_WIH, MARL_P_LB_WHH, MARL_P_LB_BIH, MARL_P_LB_BHH,              /* belief LSTM */
+    MARL_P_LA_WIH, MARL_P_LA_WHH, MARL_P_LA_BIH, MARL_P_LA_BHH,              /* action LSTM */
+    MARL_P_POL_W0, MARL_P_POL_B0, MARL_P_POL_LNW, MARL_P_POL_LNB, MARL_P_POL_W1, MARL_P_POL_B1,
+    MARL_P_CRI_W0, MARL_P_CRI_B0, MARL_P_CRI_LNW, MARL_P_CRI_LNB, MARL_P_CRI_W1, MARL_P_CRI_B1,
+    MARL_P_PRE_W0, MARL_P_PRE_B0, MARL_P_PRE_LNW, MARL_P_PRE_LNB, MARL_P_PRE_W1, MARL_P_PRE_B1,
+    MARL_NPARAMS
+};
+
+int marl_abi_version(void);
+const char* marl_last_error(void);
+
+/* Number of fp32 elements of parameter `index` for `cfg` (0 for unused slots). */
+int64_t marl_param_numel(const marl_config* cfg, int index);
+
+/* Byte sizes of the two caller-owned workspaces:
+ *   weights_ws : padded / transposed copies of the parameters + packed gradients
+ *   episode_ws : every per-step activation of one episode (saved for backward)
+ * `train` = 0 sizes episode_ws for rollout only (nothing kept for backward). */
+int marl_workspace_sizes(const marl_config* cfg, int train,
+                         size_t* weights_ws_bytes, size_t* episode_ws_bytes);
+
+/* Re-packs the parameters into weights_ws; call after every optimiser step and
+ * after load_state_dict (replaces nothing in the reference - layout plumbing). */
+int marl_pack_weights(const marl_config* cfg, const float* const* params_host,
+                      void* weights_ws, void* stream);
+
+/* Environment.__observation (core/environment.py:95-126): coalesced patch gather.
+ * img [Nb,C,H,W] fp32, pos int64 [Na*Nb,2] -> obs [Na*Nb, C, f, f] fp32. */
+int marl_patch_gather(const float* img, const int64_t* pos, float* obs,
+                      int nb_agents, int batch, int c, int h, int w, int f, void* stream);
+
+/* Environment.step / __transition (core/environment.py:56-66,128-150):
+ * pos' = pos + table[a] if the move stays inside [0, size - f) in every dim, else pos.
+ * table_host: nb_action x 2 int32 on the HOST. pos_in/pos_out int64 [rows,2] (may alias). */
+int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_out,
+                    const int32_t* table_host, int nb_action, int rows,
+                    int h, int w, int f, void* stream);
+
+/* EpisodeSampler.__episode_impl (core/episode.py:32-82) with the reference's random
+ * draws as INPUTS: pos0 int64 [R,2]; h0,c0 [R,n_b]; hc0,cc0 [R,n_a];
+ * noise [Ns,R,nA] ~ Exp(1) (th.multinomial == argmax(p / noise)).
+ * forced_actions (int64 [Ns,R]) may be NULL; if given it replaces sampling.
+ * Outputs: step_preds [Ns,R,nC], step_logp [Ns,R], step_values [Ns,R],
+ * step_pos int64 [Ns,R,2] (after move t), step_actions int64 [Ns,R] (may be NULL).
+ * With train != 0 the activations needed by marl_episode_backward stay in episode_ws. */
+int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+                         const float* img, const int64_t* pos0,
+                         const float* h0, const float* c0, const float* hc0, const float* cc0,
+                         const float* noise, const int64_t* forced_actions,
+                         float* step_preds, float* step_logp, float* step_values,
+                         int64_t* step_pos, int64_t* step_actions,
+                         int train, void* stream);
+
+/* loss.backward() through the episode (training/trainer.py:115): given dL/d(step_preds)
+ * [Ns,R,nC], dL/d(step_logp) [Ns,R], dL/d(step_values) [Ns,R] (any may be NULL = zero),
+ * writes dL/d(param) for every parameter into grads_host[i] (tight reference shapes,
+ * overwritten, not accumulated). */
+int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
+                          const float* g_preds, const float* g_logp, const float* g_values,
+                          float* const* grads_host, void* stream);
+
+/* Loss of Trainer.train_epoch (training/trainer.py:76-111; training/functions.py:7-55)
+ * and its gradient w.r.t. the episode outputs in one pass.
+ * y int64 [Nb].  scalars_out[4] = {loss, path, error, critic} (trainer.py:111,119-122).
+ * stats_inout: optional (n, sum, sumsq) hook for exact multi-GPU standardize:
+ *   phase 0 = everything local (single GPU); phase 1 = only write local
+ *   (n, sum x, sum x^2) of the advantages to adv_stats[3] (caller all-reduces them);
+ *   phase 2 = finish using the all-reduced adv_stats. */
+int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws,
+                          const float* step_preds, const float* step_logp,
+                          const float* step_values, const int64_t* y, float gamma,
+                          float* g_preds, float* g_logp, float* g_values,
+                          float* scalars_out, double* adv_stats, int phase, void* stream);
+
+/* th.optim.Adam.step (training/trainer.py:33,116) on one flat buffer:
+ * betas (0.9, 0.999), eps 1e-8, no weight decay; `step` is 1-based. grad_scale
+ * multiplies the gradient first (1/world_size after an all-reduce sum). */
+int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                   float grad_scale, void* stream);
+
+/* ModelsWrapper.forward + MultiAgent.act for ONE step used standalone
+ * (networks/models.py:78-138, core/agent.py:40-68): obs [R,C,f,f] is gathered by the
+ * caller (marl_patch_gather); msg [R,n_m]; norm_pos [R,2]; state in h,c,hc,cc.
+ * Outputs: probs [R,nA], values [R], preds [R,nC], new_msg [R,n_m], new state. */
+int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+                      const float* obs, const float* msg, const float* norm_pos,
+                      const float* h, const float* c, const float* hc, const float* cc,
+                      float* probs, float* values, float* preds, float* new_msg,
+                      float* h_out, float* c_out, float* hc_out, float* cc_out, void* stream);
+
+/* ---- kernel-level entry points (used by tests/ and profiling; same kernels) ---- */
+/* C[M,N] (+)= A[M,K] * B[N,K]^T + bias ; lda/ldb multiples of 4, 16-byte aligned. */
+int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* bias,
+                 float* c, int ldc, int m, int n, int k, int accumulate, void* stream);
+/* C[NI,NJ] = sum_r A[r,i] * B[r,j] over `rows` rows; scratch >= marl_gemm_tn_scratch(). */
+int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc,
+                 int ni, int nj, int64_t rows, float* scratch, size_t scratch_bytes, void* stream);
+size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows);
+int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta,
+                     float* out, int ldo, float* stats, int m, int n, void* stream);
+
+/* test hook: float offset and leading dimension of a named per-step activation inside
+ * episode_ws ("U","H","C","HC","CC","MSG","PROBS","COLS0","Z0","GB","DU","DH","DHC"). */
+int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t,
+                      int64_t* offset_floats, int* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARL_HIP_H */

@@ -1,0 +1,228 @@
+// Internal declarations shared by the HIP translation units of libmarl_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/marl_hip.h"
+
+namespace marl {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+inline int p4(int x) { return (x + 3) & ~3; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+void set_error(const char* fmt, ...);
+
+#define MARL_HIP_CHECK(expr)                                                        \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            marl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                            __FILE__, __LINE__);                                    \
+            return MARL_EHIP;                                                       \
+        }                                                                           \
+    } while (0)
+
+#define MARL_LAUNCH_CHECK() MARL_HIP_CHECK(hipGetLastError())
+
+#define MARL_TRY(expr)             \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != MARL_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// GEMM problem descriptors (gemm.hip)
+// ---------------------------------------------------------------------------
+// C[M,N] (+)= sum over segments s of A_s[M,K_s] * B_s[N,K_s]^T  (+ bias[N])
+// Both operands are K-contiguous ("NT"): lda/ldb are multiples of 4 floats, bases
+// 16-byte aligned, and columns [K_s, round4(K_s)) of both are zero.
+struct GemmSeg {
+    const float* a;
+    const float* b;
+    int lda, ldb, k;
+};
+
+struct GemmProb {
+    GemmSeg seg[2];
+    int nseg;
+    int m, n;
+    float* c;
+    int ldc;
+    const float* bias;
+    int accumulate;  // C += result
+    // fused LSTM-cell epilogue (gate rows of B are g * n + unit, g = i,f,g,o)
+    const float* c_prev;
+    float* h_next;
+    float* c_next;
+    float* gates;  // [M, ld_gates]: activated i | f | g | o
+    int ld_state, ld_gates;
+};
+
+constexpr int kMaxGemmBatch = 4;
+struct GemmBatch {
+    GemmProb p[kMaxGemmBatch];
+    int count;
+};
+
+GemmProb gemm_prob(const float* a, int lda, const float* b, int ldb, int k, float* c, int ldc,
+                   int m, int n, const float* bias = nullptr, int accumulate = 0);
+void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb, int k);
+
+int launch_gemm_nt(const GemmBatch& batch, hipStream_t st);
+// LSTM cell: gates = seg products + bias over 4*n_units rows of B, then the cell update.
+int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st);
+
+// C[NI,NJ] = sum_r A[r,i] * B[r,j]  (weight gradients; contraction over rows).
+size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows);
+int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
+                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// row-wise kernels (rowops.hip)
+// ---------------------------------------------------------------------------
+int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
+                       int ldo, float* stats, int64_t m, int n, hipStream_t st);
+// dz = d(loss)/d(z) from da = d(loss)/d(silu out); dgamma/dbeta partial sums are written
+// to part[nblk][2][n]; returns nblk through *nblk_out.
+int ln_bwd_blocks(int64_t m);
+int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
+                       const float* gamma, const float* beta, float* dz, int lddz, float* part,
+                       int64_t m, int n, hipStream_t st);
+// out[n] (+)= sum over p of part[p][n]   (fixed order -> deterministic)
+int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, float* out, int n,
+                           int accumulate, hipStream_t st);
+// LayerNorm/GroupNorm partials [nparts][2][n] -> dgamma[n], dbeta[n]
+int launch_reduce_affine(const float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
+                         int accumulate, hipStream_t st);
+// out[n] = sum over rows of x[r][n]; scratch holds colsum_blocks(rows) * n floats
+int colsum_blocks(int64_t rows);
+int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float* scratch,
+                  hipStream_t st);
+
+// GroupNorm + SiLU over NHWC rows: z [rows, P, C] -> a.  out_chw != 0 writes element
+// (pos, c) at out[row * ldo + c * P + pos] (reference Flatten order), else NHWC with ldo = P*C.
+int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
+                       int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
+                       hipStream_t st);
+int gn_bwd_blocks(int64_t rows);
+int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
+                       const float* stats, const float* gamma, const float* beta, float* dz,
+                       float* part, int64_t rows, int P, int C, int G, hipStream_t st);
+
+// message mean over the other agents (networks/message.py:5-17); self-adjoint, so the
+// same kernel is its own backward.
+int launch_agg_msg(const float* m, float* out, int ld, int na, int nb, int n, hipStream_t st);
+
+// map_pos (networks/state.py): lambda = SiLU(LN(W * (pos / size) + b)) -> out (ld ldo)
+// (npos_in != null: use these normalised positions [rows,2] instead of pos / size)
+int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w, const float* W, const float* b,
+                         const float* gamma, const float* beta, float* npos4, float* z, int ldz,
+                         float* stats, float* out, int ldo, int64_t rows, int nd, hipStream_t st);
+
+int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
+                         const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
+                         hipStream_t st);
+
+struct SampleArgs {
+    const float* a_pol;  // [R, ld_a] SiLU(LN(policy hidden))
+    int ld_a, nla;
+    const float* w1;  // packed [nA, ldw]
+    int ldw;
+    const float* b1;
+    const float* noise;            // [R, nA]
+    const int64_t* forced;         // [R] or null
+    const int32_t* pos_in;         // [R, 2]
+    int32_t* pos_out;              // [R, 2]
+    int64_t* step_pos;             // [R, 2] or null
+    int64_t* step_actions;         // [R] or null
+    float* step_logp;              // [R]
+    float* probs;                  // [R, nA] saved
+    int32_t* actions_i32;          // [R] saved
+    int R, nA, H, W, f;
+    int32_t table[MARL_MAX_ACTIONS][2];
+};
+int launch_sample(const SampleArgs& a, hipStream_t st);
+
+// generic permuted copies used by pack / unpack
+struct PermDesc {
+    const float* src;
+    float* dst;
+    int rows, cols;      // dst logical extent
+    int dst_ld;
+    int rd, rs1, rs2;    // src offset = (r / rd) * rs1 + (r % rd) * rs2
+    int cd, cs1, cs2;    //            + (c / cd) * cs1 + (c % cd) * cs2
+    const float* src2;   // optional: dst = src + src2 (same indexing), e.g. b_ih + b_hh
+};
+constexpr int kMaxPerm = 24;
+struct PermBatch {
+    PermDesc d[kMaxPerm];
+    int count;
+};
+int launch_permute(const PermBatch& b, hipStream_t st);
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_over_bc1,
+                float inv_sqrt_bc2, float beta1, float beta2, float eps, float grad_scale,
+                hipStream_t st);
+
+// elementwise helpers
+int launch_fill(float* p, int64_t n, float v, hipStream_t st);
+int launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
+                  hipStream_t st);
+int launch_i64_to_i32(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);
+// dlogits[r][j] = dlogp[r] * (1[j == a_r] - p[r][j]) into [R, ld] (cols >= nA untouched)
+int launch_policy_dlogits(const float* dlogp, const float* probs, const int32_t* actions,
+                          float* out, int ld, int64_t rows, int nA, hipStream_t st);
+// values[r] = dot(a[r,:n], w[:n]) + b
+int launch_rowdot(const float* a, int lda, const float* w, const float* b, float* out,
+                  int64_t rows, int n, hipStream_t st);
+// softmax rows in place helper for the standalone step API
+int launch_softmax_rows(const float* logits, int ld, float* probs, int64_t rows, int n,
+                        hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// CNN data movement (cnn.hip)
+// ---------------------------------------------------------------------------
+// Patch gather fused with the first layer's im2col: img [Nb,Cimg,H,W], pos int32 [R,2]
+// -> cols [R * P, ldk], k = (kh*3+kw)*cin + ci, P = oh*ow, oh = (f-1)/2+1.
+int launch_gather_im2col(const float* img, const int32_t* pos, float* cols, int ldk, int na,
+                         int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
+// same but from pre-gathered patches obs [R, c_img, f, f] (standalone step API)
+int launch_obs_im2col(const float* obs, float* cols, int ldk, int64_t rows, int c_img, int cin,
+                      int f, hipStream_t st);
+// plain gather (Environment.observe): obs [R, C, f, f]
+int launch_patch_gather(const float* img, const int64_t* pos, float* obs, int na, int nb, int c,
+                        int H, int W, int f, hipStream_t st);
+// NHWC activation [rows, hin, hin, cin] -> cols [rows * hout^2, ldk]
+int launch_im2col(const float* a, float* cols, int ldk, int64_t rows, int hin, int cin,
+                  hipStream_t st);
+// transpose of the above: dcols -> da (gather form, deterministic)
+int launch_col2im(const float* dcols, int ldk, float* da, int64_t rows, int hin, int cin,
+                  hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// loss (loss.hip)
+// ---------------------------------------------------------------------------
+struct LossArgs {
+    const float* preds;   // [Ns, Na, Nb, nC]
+    const float* logp;    // [Ns, Na, Nb]
+    const float* values;  // [Ns, Na, Nb]
+    const int64_t* y;     // [Nb]
+    float* g_preds;       // [Ns*R, ld_gp]
+    int ld_gp;
+    float* g_logp;
+    float* g_values;
+    float* scalars;  // [4]
+    double* adv_stats;  // [3] = n, sum, sum of squares of the advantages
+    float* scratch;  // returns/adv [2][Ns*R] + partial sums
+    int ns, na, nb, nc;
+    float gamma;
+    int phase;
+};
+size_t loss_scratch_floats(int ns, int na, int nb);
+int launch_loss(const LossArgs& a, hipStream_t st);
+
+}  // namespace marl

@@ -1,0 +1,1169 @@
+// Host-side orchestration of the episode (EpisodeSampler.__episode_impl,
+// core/episode.py:32-82) and of loss.backward() through it, plus the C ABI of
+// include/marl_hip.h.  Everything here only computes buffer layouts inside the two
+// caller-owned workspaces and enqueues kernels on the caller's stream.
+//
+// Structure of one training iteration (R = Na*Nb rows, r = a*Nb + b):
+//   forward, t = 0..Ns-1 (strictly sequential: positions depend on sampled actions)
+//     gather+im2col -> [conv GEMM -> GroupNorm+SiLU -> im2col]*  -> b_t  into U[t]
+//     message mean -> decode MLP -> d_t into U[t];  position embedding -> lambda_t into U[t]
+//     belief + action LSTM: one grouped MFMA GEMM with the cell update fused in the epilogue
+//     encode MLP -> msg_{t+1};  policy hidden -> output layer + softmax + sample + move
+//   after the loop (batched over all Ns*R rows, better GEMM shapes):
+//     critic and prediction heads on the saved h / h^ of every step
+//   backward: heads batched first (their inputs' gradients do not depend on the recurrence),
+//     then the reverse-time loop over only the recurrent chain (LSTM cells, message
+//     decode/encode), then every weight gradient as ONE row-contraction GEMM over all
+//     Ns*R rows, the full dU, and the CNN backward batched over all steps.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace marl {
+
+// ---------------------------------------------------------------------------
+// dimensions
+// ---------------------------------------------------------------------------
+struct Dims {
+    int na, nb, ns;
+    int64_t R, NR;
+    int H, W, c_img, f;
+    int L;
+    int ch[MARL_MAX_CNN_LAYERS + 1];
+    int grp[MARL_MAX_CNN_LAYERS];
+    int hw[MARL_MAX_CNN_LAYERS + 1];  // spatial size entering layer l (hw[0] = f)
+    int P[MARL_MAX_CNN_LAYERS];       // output positions of layer l
+    int K[MARL_MAX_CNN_LAYERS];       // 9 * cin
+    int ldk[MARL_MAX_CNN_LAYERS];
+    int nf, nin;
+    int n_b, n_a, n_m, nm2, n_mo, n_d, nA, nC, nlb, nla;
+    int ld_nin, ld_nb, ld_na, ld_nm, ld_nm2, ld_nmo, ld_nd, ld_nla, ld_nlb, ld_gb, ld_ga, ld_nC,
+        ld_nA;
+};
+
+static int make_dims(const marl_config* c, Dims& d) {
+    if (!c) {
+        set_error("null config");
+        return MARL_EINVAL;
+    }
+    memset(&d, 0, sizeof(d));
+    d.na = c->nb_agents;
+    d.nb = c->batch;
+    d.ns = c->nb_steps;
+    d.H = c->img_h;
+    d.W = c->img_w;
+    d.c_img = c->img_c;
+    d.f = c->window;
+    d.L = c->cnn_layers;
+    if (d.na < 1 || d.nb < 1 || d.ns < 1 || d.f < 1 || d.H <= d.f || d.W <= d.f || d.c_img < 1) {
+        set_error("bad episode shape na=%d nb=%d ns=%d f=%d img=%dx%dx%d", d.na, d.nb, d.ns, d.f,
+                  d.c_img, d.H, d.W);
+        return MARL_EINVAL;
+    }
+    if (d.L < 1 || d.L > MARL_MAX_CNN_LAYERS) {
+        set_error("cnn_layers %d outside [1,%d]", d.L, MARL_MAX_CNN_LAYERS);
+        return MARL_ELIMIT;
+    }
+    d.R = (int64_t)d.na * d.nb;
+    d.NR = d.R * d.ns;
+    d.hw[0] = d.f;
+    for (int l = 0; l <= d.L; ++l) d.ch[l] = c->cnn_ch[l];
+    if (d.ch[0] < 1 || d.ch[0] > d.c_img) {
+        set_error("cnn input channels %d vs image channels %d", d.ch[0], d.c_img);
+        return MARL_EINVAL;
+    }
+    for (int l = 0; l < d.L; ++l) {
+        d.grp[l] = c->cnn_groups[l];
+        if (d.ch[l + 1] < 1 || d.grp[l] < 1 || d.ch[l + 1] % d.grp[l] != 0 || (d.ch[l + 1] & 3)) {
+            set_error("cnn layer %d: %d channels / %d groups unsupported (channels must be a "
+                      "multiple of 4 and of the group count)", l, d.ch[l + 1], d.grp[l]);
+            return MARL_ELIMIT;
+        }
+        d.hw[l + 1] = (d.hw[l] - 1) / 2 + 1;
+        d.P[l] = d.hw[l + 1] * d.hw[l + 1];
+        d.K[l] = 9 * d.ch[l];
+        d.ldk[l] = p4(d.K[l]);
+    }
+    d.nf = d.ch[d.L] * d.P[d.L - 1];
+    d.n_b = c->n_b;
+    d.n_a = c->n_a;
+    d.n_m = c->n_m;
+    d.nm2 = 2 * c->n_m;
+    d.n_mo = c->n_m_o;
+    d.n_d = c->n_d;
+    d.nA = c->nb_action;
+    d.nC = c->nb_class;
+    d.nlb = c->nlb;
+    d.nla = c->nla;
+    if (d.n_b < 1 || d.n_a < 1 || d.n_m < 1 || d.n_mo < 1 || d.n_d < 1 || d.nA < 1 || d.nC < 1 ||
+        d.nlb < 1 || d.nla < 1) {
+        set_error("non-positive hidden size");
+        return MARL_EINVAL;
+    }
+    if (d.nA > MARL_MAX_ACTIONS || d.nC > 1024 || d.nlb > 2048 || d.nla > 2048 || d.nm2 > 2048 ||
+        d.n_mo > 2048 || d.n_d > 2048) {
+        set_error("dimension above the supported range (nA<=16, nC<=1024, LayerNorm width<=2048)");
+        return MARL_ELIMIT;
+    }
+    d.nin = d.nf + d.n_mo + d.n_d;
+    d.ld_nin = p4(d.nin);
+    d.ld_nb = p4(d.n_b);
+    d.ld_na = p4(d.n_a);
+    d.ld_nm = p4(d.n_m);
+    d.ld_nm2 = p4(d.nm2);
+    d.ld_nmo = p4(d.n_mo);
+    d.ld_nd = p4(d.n_d);
+    d.ld_nla = p4(d.nla);
+    d.ld_nlb = p4(d.nlb);
+    d.ld_gb = p4(4 * d.n_b);
+    d.ld_ga = p4(4 * d.n_a);
+    d.ld_nC = p4(d.nC);
+    d.ld_nA = p4(d.nA);
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------
+enum ParamKind { PK_NONE = 0, PK_MATRIX, PK_CONV, PK_VEC };
+struct ParamMeta {
+    ParamKind kind;
+    int n, k;  // matrix [n, k]; conv [n, ci(=k/9), 3, 3]; vec [n]
+};
+
+static ParamMeta param_meta(const Dims& d, int idx) {
+    auto M = [](int n, int k) { return ParamMeta{PK_MATRIX, n, k}; };
+    auto V = [](int n) { return ParamMeta{PK_VEC, n, 1}; };
+    if (idx < 20) {
+        const int l = idx / 4, w = idx % 4;
+        if (l >= d.L) return ParamMeta{PK_NONE, 0, 0};
+        if (w == 0) return ParamMeta{PK_CONV, d.ch[l + 1], d.K[l]};
+        return V(d.ch[l + 1]);
+    }
+    switch (idx) {
+        case MARL_P_POS_W: return M(d.n_d, 2);
+        case MARL_P_POS_B: case MARL_P_POS_LNW: case MARL_P_POS_LNB: return V(d.n_d);
+        case MARL_P_ENC_W0: return M(d.nm2, d.n_b);
+        case MARL_P_ENC_B0: case MARL_P_ENC_LN0W: case MARL_P_ENC_LN0B: return V(d.nm2);
+        case MARL_P_ENC_W1: return M(d.n_m, d.nm2);
+        case MARL_P_ENC_B1: case MARL_P_ENC_LN1W: case MARL_P_ENC_LN1B: return V(d.n_m);
+        case MARL_P_DEC_W0: return M(d.nm2, d.n_m);
+        case MARL_P_DEC_B0: case MARL_P_DEC_LN0W: case MARL_P_DEC_LN0B: return V(d.nm2);
+        case MARL_P_DEC_W1: return M(d.n_mo, d.nm2);
+        case MARL_P_DEC_B1: case MARL_P_DEC_LN1W: case MARL_P_DEC_LN1B: return V(d.n_mo);
+        case MARL_P_LB_WIH: return M(4 * d.n_b, d.nin);
+        case MARL_P_LB_WHH: return M(4 * d.n_b, d.n_b);
+        case MARL_P_LB_BIH: case MARL_P_LB_BHH: return V(4 * d.n_b);
+        case MARL_P_LA_WIH: return M(4 * d.n_a, d.nin);
+        case MARL_P_LA_WHH: return M(4 * d.n_a, d.n_a);
+        case MARL_P_LA_BIH: case MARL_P_LA_BHH: return V(4 * d.n_a);
+        case MARL_P_POL_W0: return M(d.nla, d.n_a);
+        case MARL_P_POL_B0: case MARL_P_POL_LNW: case MARL_P_POL_LNB: return V(d.nla);
+        case MARL_P_POL_W1: return M(d.nA, d.nla);
+        case MARL_P_POL_B1: return V(d.nA);
+        case MARL_P_CRI_W0: return M(d.nla, d.n_a);
+        case MARL_P_CRI_B0: case MARL_P_CRI_LNW: case MARL_P_CRI_LNB: return V(d.nla);
+        case MARL_P_CRI_W1: return M(1, d.nla);
+        case MARL_P_CRI_B1: return V(1);
+        case MARL_P_PRE_W0: return M(d.nlb, d.n_b);
+        case MARL_P_PRE_B0: case MARL_P_PRE_LNW: case MARL_P_PRE_LNB: return V(d.nlb);
+        case MARL_P_PRE_W1: return M(d.nC, d.nlb);
+        case MARL_P_PRE_B1: return V(d.nC);
+        default: return ParamMeta{PK_NONE, 0, 0};
+    }
+}
+
+// bump allocator over a workspace, in floats, 64-float (256 B) aligned
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t n) {
+        const size_t o = off;
+        off += (n + 63) & ~(size_t)63;
+        return o;
+    }
+};
+
+// weights workspace: packed (padded) copy, transposed copy, packed gradient per matrix
+struct WLayout {
+    size_t wp[MARL_NPARAMS];  // packed / tight copy
+    int ldp[MARL_NPARAMS];
+    size_t wt[MARL_NPARAMS];  // transposed copy [k, p4(n)]
+    int ldt[MARL_NPARAMS];
+    size_t gp[MARL_NPARAMS];  // packed gradient (same shape as wp)
+    size_t bsum_b, bsum_a;    // b_ih + b_hh
+    size_t total;
+};
+
+static void make_wlayout(const Dims& d, WLayout& w) {
+    Bump b;
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        w.wp[i] = w.wt[i] = w.gp[i] = 0;
+        w.ldp[i] = w.ldt[i] = 0;
+        if (m.kind == PK_MATRIX || m.kind == PK_CONV) {
+            w.ldp[i] = p4(m.k);
+            w.wp[i] = b.take((size_t)m.n * w.ldp[i]);
+            w.ldt[i] = p4(m.n);
+            w.wt[i] = b.take((size_t)m.k * w.ldt[i]);
+            w.gp[i] = b.take((size_t)m.n * w.ldp[i]);
+        } else if (m.kind == PK_VEC) {
+            w.ldp[i] = m.n;
+            w.wp[i] = b.take((size_t)m.n);
+        }
+    }
+    w.bsum_b = b.take((size_t)4 * d.n_b);
+    w.bsum_a = b.take((size_t)4 * d.n_a);
+    w.total = b.off;
+}
+
+// episode workspace
+struct SBuf {  // per-step buffer: base offset + stride between steps (0 when shared)
+    size_t off = 0, stride = 0;
+    size_t at(int t) const { return off + stride * (size_t)t; }
+};
+
+struct ELayout {
+    // all-steps state
+    size_t POS;  // int32 [(Ns+1)][R][2]
+    size_t H, C, HC, CC, MSG;  // [(Ns+1)][R][ld]
+    size_t PROBS, ACT;         // [Ns][R][nA], int32 [Ns][R]
+    // per step
+    SBuf COLS[MARL_MAX_CNN_LAYERS], Z[MARL_MAX_CNN_LAYERS], GST[MARL_MAX_CNN_LAYERS],
+        A[MARL_MAX_CNN_LAYERS];
+    SBuf U, MBAR, ZD1, STD1, AD1, ZD2, STD2, NPOS, ZPOS, STPOS, GB, GA, ZE1, STE1, AE1, ZE2, STE2,
+        ZP1, STP1, AP1;
+    // batched heads
+    size_t ZC1, STC1, AC1, ZQ1, STQ1, AQ1;
+    // backward only
+    size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DAD1, DMBAR, DZE2, DAE1, DU,
+        DZPOS, BTMP;
+    size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
+    size_t PART, CSUM, TNS, LOSS;
+    size_t part_floats, csum_floats, tns_bytes, loss_floats;
+    size_t total;
+};
+
+static void make_elayout(const Dims& d, int train, ELayout& e) {
+    Bump b;
+    const size_t R = (size_t)d.R, NR = (size_t)d.NR, S1 = (size_t)d.ns + 1;
+    e.POS = b.take(S1 * R * 2);
+    e.H = b.take(S1 * R * d.ld_nb);
+    e.C = b.take(S1 * R * d.ld_nb);
+    e.HC = b.take(S1 * R * d.ld_na);
+    e.CC = b.take(S1 * R * d.ld_na);
+    e.MSG = b.take(S1 * R * d.ld_nm);
+    e.PROBS = b.take(NR * d.nA);
+    e.ACT = b.take(NR);
+    const size_t steps = train ? (size_t)d.ns : 1;
+    auto per = [&](SBuf& s, size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        s.off = b.take(n * steps);
+        s.stride = train ? n : 0;
+    };
+    for (int l = 0; l < d.L; ++l) {
+        per(e.COLS[l], R * d.P[l] * d.ldk[l]);
+        per(e.Z[l], R * d.P[l] * d.ch[l + 1]);
+        per(e.GST[l], R * d.grp[l] * 2);
+        if (l + 1 < d.L) per(e.A[l], R * d.P[l] * d.ch[l + 1]);
+    }
+    per(e.U, R * d.ld_nin);
+    per(e.MBAR, R * d.ld_nm);
+    per(e.ZD1, R * d.ld_nm2);
+    per(e.STD1, R * 2);
+    per(e.AD1, R * d.ld_nm2);
+    per(e.ZD2, R * d.ld_nmo);
+    per(e.STD2, R * 2);
+    per(e.NPOS, R * 4);
+    per(e.ZPOS, R * d.ld_nd);
+    per(e.STPOS, R * 2);
+    per(e.GB, R * d.ld_gb);
+    per(e.GA, R * d.ld_ga);
+    per(e.ZE1, R * d.ld_nm2);
+    per(e.STE1, R * 2);
+    per(e.AE1, R * d.ld_nm2);
+    per(e.ZE2, R * d.ld_nm);
+    per(e.STE2, R * 2);
+    per(e.ZP1, R * d.ld_nla);
+    per(e.STP1, R * 2);
+    per(e.AP1, R * d.ld_nla);
+    e.ZC1 = b.take(NR * d.ld_nla);
+    e.STC1 = b.take(NR * 2);
+    e.AC1 = b.take(NR * d.ld_nla);
+    e.ZQ1 = b.take(NR * d.ld_nlb);
+    e.STQ1 = b.take(NR * 2);
+    e.AQ1 = b.take(NR * d.ld_nlb);
+    e.part_floats = e.csum_floats = e.tns_bytes = e.loss_floats = 0;
+    if (train) {
+        e.GPRED = b.take(NR * d.ld_nC);
+        e.DLOG = b.take(NR * d.ld_nA);
+        e.DVAL = b.take(NR * 4);
+        e.DAQ1 = b.take(NR * d.ld_nlb);
+        e.DAC1 = b.take(NR * d.ld_nla);
+        e.DAP1 = b.take(NR * d.ld_nla);
+        e.DH = b.take(S1 * R * d.ld_nb);
+        e.DHC = b.take(S1 * R * d.ld_na);
+        e.DC = b.take(R * d.ld_nb);
+        e.DCC = b.take(R * d.ld_na);
+        e.DDBAR = b.take(NR * d.ld_nmo);
+        e.DAD1 = b.take(NR * d.ld_nm2);
+        e.DMBAR = b.take(R * d.ld_nm);
+        e.DZE2 = b.take(NR * d.ld_nm);
+        e.DAE1 = b.take(NR * d.ld_nm2);
+        e.DU = b.take(NR * d.ld_nin);
+        e.DZPOS = b.take(NR * d.ld_nd);
+        int maxg = 4 * (d.n_b > d.n_a ? d.n_b : d.n_a);
+        e.BTMP = b.take((size_t)maxg);
+        for (int l = 0; l < d.L; ++l) {
+            e.DZ[l] = b.take(NR * d.P[l] * d.ch[l + 1]);
+            e.DCOLS[l] = l > 0 ? b.take(NR * d.P[l] * d.ldk[l]) : 0;
+            e.DA[l] = (l + 1 < d.L) ? b.take(NR * d.P[l] * d.ch[l + 1]) : 0;
+        }
+        // scratch sizes: maxima over every use
+        size_t part = 0, csum = 0, tns = 0;
+        auto upd_part = [&](int64_t blocks, int n) {
+            const size_t v = (size_t)blocks * 2 * n;
+            part = v > part ? v : part;
+        };
+        auto upd_cs = [&](int64_t rows, int n) {
+            const size_t v = (size_t)colsum_blocks(rows) * n;
+            csum = v > csum ? v : csum;
+        };
+        auto upd_tn = [&](int ni, int nj, int64_t rows) {
+            const size_t v = gemm_tn_scratch_bytes(ni, nj, rows);
+            tns = v > tns ? v : tns;
+        };
+        const int64_t nr = d.NR, r = d.R;
+        upd_part(ln_bwd_blocks(nr), d.nlb);
+        upd_part(ln_bwd_blocks(nr), d.nla);
+        upd_part(ln_bwd_blocks(nr), d.n_d);
+        upd_part(ln_bwd_blocks(r), d.nm2);
+        upd_part(ln_bwd_blocks(r), d.n_mo);
+        upd_part(ln_bwd_blocks(r), d.n_m);
+        for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr), d.ch[l + 1]);
+        int widths[] = {d.nC, d.nlb, d.nla, 4, d.nA, d.n_mo, d.nm2, d.n_m, 4 * d.n_b, 4 * d.n_a, d.n_d};
+        for (int wv : widths) upd_cs(nr, wv);
+        for (int l = 0; l < d.L; ++l) upd_cs(nr * d.P[l], d.ch[l + 1]);
+        upd_tn(d.nC, d.nlb, nr);
+        upd_tn(d.nlb, d.n_b, nr);
+        upd_tn(1, d.nla, nr);
+        upd_tn(d.nla, d.n_a, nr);
+        upd_tn(d.nA, d.nla, nr);
+        upd_tn(d.n_mo, d.nm2, nr);
+        upd_tn(d.nm2, d.n_m, nr);
+        upd_tn(d.n_m, d.nm2, nr);
+        upd_tn(d.nm2, d.n_b, nr);
+        upd_tn(4 * d.n_b, d.nin, nr);
+        upd_tn(4 * d.n_b, d.n_b, nr);
+        upd_tn(4 * d.n_a, d.nin, nr);
+        upd_tn(4 * d.n_a, d.n_a, nr);
+        upd_tn(d.n_d, 2, nr);
+        for (int l = 0; l < d.L; ++l) upd_tn(d.ch[l + 1], d.K[l], nr * d.P[l]);
+        e.part_floats = part;
+        e.csum_floats = csum;
+        e.tns_bytes = tns;
+        e.PART = b.take(part);
+        e.CSUM = b.take(csum);
+        e.TNS = b.take(tns / sizeof(float) + 16);
+    }
+    e.loss_floats = loss_scratch_floats(d.ns, d.na, d.nb);
+    e.LOSS = b.take(e.loss_floats);
+    e.total = b.off;
+}
+
+// ---------------------------------------------------------------------------
+// context shared by the forward / backward drivers
+// ---------------------------------------------------------------------------
+struct Ctx {
+    Dims d;
+    WLayout w;
+    ELayout e;
+    float* W;  // weights workspace
+    float* E;  // episode workspace
+    hipStream_t st;
+    int train;
+
+    const float* wp(int i) const { return W + w.wp[i]; }
+    const float* wt(int i) const { return W + w.wt[i]; }
+    float* gp(int i) const { return W + w.gp[i]; }
+    float* at(size_t off) const { return E + off; }
+    float* at(const SBuf& s, int t) const { return E + s.at(train ? t : 0); }
+    // all-steps buffers, slice t
+    float* Hs(int t) const { return E + e.H + (size_t)t * d.R * d.ld_nb; }
+    float* Cs(int t) const { return E + e.C + (size_t)t * d.R * d.ld_nb; }
+    float* HCs(int t) const { return E + e.HC + (size_t)t * d.R * d.ld_na; }
+    float* CCs(int t) const { return E + e.CC + (size_t)t * d.R * d.ld_na; }
+    float* MSGs(int t) const { return E + e.MSG + (size_t)t * d.R * d.ld_nm; }
+    int32_t* POSs(int t) const { return reinterpret_cast<int32_t*>(E + e.POS) + (size_t)t * d.R * 2; }
+    float* PROBSs(int t) const { return E + e.PROBS + (size_t)t * d.R * d.nA; }
+    int32_t* ACTs(int t) const { return reinterpret_cast<int32_t*>(E + e.ACT) + (size_t)t * d.R; }
+    float* DHs(int t) const { return E + e.DH + (size_t)t * d.R * d.ld_nb; }
+    float* DHCs(int t) const { return E + e.DHC + (size_t)t * d.R * d.ld_na; }
+};
+
+static int make_ctx(const marl_config* cfg, const void* wws, void* ews, int train, void* stream,
+                    Ctx& c) {
+    MARL_TRY(make_dims(cfg, c.d));
+    make_wlayout(c.d, c.w);
+    make_elayout(c.d, train, c.e);
+    c.W = const_cast<float*>(static_cast<const float*>(wws));
+    c.E = static_cast<float*>(ews);
+    c.st = static_cast<hipStream_t>(stream);
+    c.train = train;
+    if (!c.W || !c.E) {
+        set_error("null workspace");
+        return MARL_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(c.W) & 255) || (reinterpret_cast<uintptr_t>(c.E) & 255)) {
+        set_error("workspaces must be 256-byte aligned");
+        return MARL_EINVAL;
+    }
+    return MARL_OK;
+}
+
+static int gemm1(const Ctx& c, const GemmProb& p) {
+    GemmBatch b{};
+    b.p[0] = p;
+    b.count = 1;
+    return launch_gemm_nt(b, c.st);
+}
+static int gemm2(const Ctx& c, const GemmProb& p0, const GemmProb& p1) {
+    GemmBatch b{};
+    b.p[0] = p0;
+    b.p[1] = p1;
+    b.count = 2;
+    return launch_gemm_nt(b, c.st);
+}
+
+// ---------------------------------------------------------------------------
+// one step of the network up to (not including) the policy output layer
+// ---------------------------------------------------------------------------
+struct StepIn {
+    const float* obs = nullptr;       // standalone API: pre-gathered patches
+    const float* npos = nullptr;      // standalone API: normalised positions
+    const float* img = nullptr;
+};
+
+static int step_core(const Ctx& c, int t, const StepIn& in) {
+    const Dims& d = c.d;
+    const int R = (int)d.R;
+    hipStream_t st = c.st;
+    // --- observation -> CNN features b_t (networks/vision.py:23-52)
+    if (in.obs)
+        MARL_TRY(launch_obs_im2col(in.obs, c.at(c.e.COLS[0], t), d.ldk[0], d.R, d.c_img, d.ch[0],
+                                   d.f, st));
+    else
+        MARL_TRY(launch_gather_im2col(in.img, c.POSs(t), c.at(c.e.COLS[0], t), d.ldk[0], d.na, d.nb,
+                                      d.c_img, d.ch[0], d.H, d.W, d.f, st));
+    for (int l = 0; l < d.L; ++l) {
+        const int co = d.ch[l + 1];
+        const int64_t rows = d.R * d.P[l];
+        MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.COLS[l], t), d.ldk[l], c.wp(4 * l), d.ldk[l], d.K[l],
+                                    c.at(c.e.Z[l], t), co, (int)rows, co, c.wp(4 * l + 1))));
+        if (l + 1 < d.L) {
+            MARL_TRY(launch_gn_silu_fwd(c.at(c.e.Z[l], t), c.wp(4 * l + 2), c.wp(4 * l + 3),
+                                        c.at(c.e.A[l], t), (int64_t)d.P[l] * co, 0,
+                                        c.at(c.e.GST[l], t), d.R, d.P[l], co, d.grp[l], st));
+            MARL_TRY(launch_im2col(c.at(c.e.A[l], t), c.at(c.e.COLS[l + 1], t), d.ldk[l + 1], d.R,
+                                   d.hw[l + 1], co, st));
+        } else {
+            MARL_TRY(launch_gn_silu_fwd(c.at(c.e.Z[l], t), c.wp(4 * l + 2), c.wp(4 * l + 3),
+                                        c.at(c.e.U, t), d.ld_nin, 1, c.at(c.e.GST[l], t), d.R,
+                                        d.P[l], co, d.grp[l], st));
+        }
+    }
+    // --- messages: mean over the other agents, decode (networks/models.py:97-98)
+    MARL_TRY(launch_agg_msg(c.MSGs(t), c.at(c.e.MBAR, t), d.ld_nm, d.na, d.nb, d.n_m, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.MBAR, t), d.ld_nm, c.wp(MARL_P_DEC_W0), p4(d.n_m), d.n_m,
+                                c.at(c.e.ZD1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_DEC_B0))));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZD1, t), d.ld_nm2, c.wp(MARL_P_DEC_LN0W),
+                                c.wp(MARL_P_DEC_LN0B), c.at(c.e.AD1, t), d.ld_nm2,
+                                c.at(c.e.STD1, t), d.R, d.nm2, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AD1, t), d.ld_nm2, c.wp(MARL_P_DEC_W1), d.ld_nm2, d.nm2,
+                                c.at(c.e.ZD2, t), d.ld_nmo, R, d.n_mo, c.wp(MARL_P_DEC_B1))));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZD2, t), d.ld_nmo, c.wp(MARL_P_DEC_LN1W),
+                                c.wp(MARL_P_DEC_LN1B), c.at(c.e.U, t) + d.nf, d.ld_nin,
+                                c.at(c.e.STD2, t), d.R, d.n_mo, st));
+    // --- position embedding (networks/models.py:101)
+    MARL_TRY(launch_pos_embed_fwd(c.POSs(t), in.npos, d.H, d.W, c.wp(MARL_P_POS_W),
+                                  c.wp(MARL_P_POS_B), c.wp(MARL_P_POS_LNW), c.wp(MARL_P_POS_LNB),
+                                  c.at(c.e.NPOS, t), c.at(c.e.ZPOS, t), d.ld_nd, c.at(c.e.STPOS, t),
+                                  c.at(c.e.U, t) + d.nf + d.n_mo, d.ld_nin, d.R, d.n_d, st));
+    // --- belief + action LSTM cells (networks/models.py:107-123), one grouped launch
+    {
+        GemmBatch b{};
+        b.count = 2;
+        GemmProb& pb = b.p[0];
+        pb = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LB_WIH), d.ld_nin, d.nin, nullptr, 0, R,
+                       d.n_b, c.W + c.w.bsum_b);
+        gemm_add_seg(pb, c.Hs(t), d.ld_nb, c.wp(MARL_P_LB_WHH), d.ld_nb, d.n_b);
+        pb.c_prev = c.Cs(t);
+        pb.h_next = c.Hs(t + 1);
+        pb.c_next = c.Cs(t + 1);
+        pb.gates = c.train ? c.at(c.e.GB, t) : nullptr;
+        pb.ld_state = d.ld_nb;
+        pb.ld_gates = d.ld_gb;
+        GemmProb& pa = b.p[1];
+        pa = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LA_WIH), d.ld_nin, d.nin, nullptr, 0, R,
+                       d.n_a, c.W + c.w.bsum_a);
+        gemm_add_seg(pa, c.HCs(t), d.ld_na, c.wp(MARL_P_LA_WHH), d.ld_na, d.n_a);
+        pa.c_prev = c.CCs(t);
+        pa.h_next = c.HCs(t + 1);
+        pa.c_next = c.CCs(t + 1);
+        pa.gates = c.train ? c.at(c.e.GA, t) : nullptr;
+        pa.ld_state = d.ld_na;
+        pa.ld_gates = d.ld_ga;
+        MARL_TRY(launch_gemm_lstm(b, st));
+    }
+    // --- message encoder and policy hidden layer (networks/models.py:114-128)
+    MARL_TRY(gemm2(c,
+                   gemm_prob(c.Hs(t + 1), d.ld_nb, c.wp(MARL_P_ENC_W0), d.ld_nb, d.n_b,
+                             c.at(c.e.ZE1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_ENC_B0)),
+                   gemm_prob(c.HCs(t + 1), d.ld_na, c.wp(MARL_P_POL_W0), d.ld_na, d.n_a,
+                             c.at(c.e.ZP1, t), d.ld_nla, R, d.nla, c.wp(MARL_P_POL_B0))));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE1, t), d.ld_nm2, c.wp(MARL_P_ENC_LN0W),
+                                c.wp(MARL_P_ENC_LN0B), c.at(c.e.AE1, t), d.ld_nm2,
+                                c.at(c.e.STE1, t), d.R, d.nm2, st));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZP1, t), d.ld_nla, c.wp(MARL_P_POL_LNW),
+                                c.wp(MARL_P_POL_LNB), c.at(c.e.AP1, t), d.ld_nla,
+                                c.at(c.e.STP1, t), d.R, d.nla, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AE1, t), d.ld_nm2, c.wp(MARL_P_ENC_W1), d.ld_nm2, d.nm2,
+                                c.at(c.e.ZE2, t), d.ld_nm, R, d.n_m, c.wp(MARL_P_ENC_B1))));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE2, t), d.ld_nm, c.wp(MARL_P_ENC_LN1W),
+                                c.wp(MARL_P_ENC_LN1B), c.MSGs(t + 1), d.ld_nm, c.at(c.e.STE2, t),
+                                d.R, d.n_m, st));
+    return MARL_OK;
+}
+
+// critic + prediction heads on `rows` rows starting at state slice t0 (+1)
+static int heads_batched(const Ctx& c, int t0, int64_t rows, float* values, float* preds) {
+    const Dims& d = c.d;
+    hipStream_t st = c.st;
+    MARL_TRY(gemm2(c,
+                   gemm_prob(c.HCs(t0 + 1), d.ld_na, c.wp(MARL_P_CRI_W0), d.ld_na, d.n_a,
+                             c.at(c.e.ZC1), d.ld_nla, (int)rows, d.nla, c.wp(MARL_P_CRI_B0)),
+                   gemm_prob(c.Hs(t0 + 1), d.ld_nb, c.wp(MARL_P_PRE_W0), d.ld_nb, d.n_b,
+                             c.at(c.e.ZQ1), d.ld_nlb, (int)rows, d.nlb, c.wp(MARL_P_PRE_B0))));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZC1), d.ld_nla, c.wp(MARL_P_CRI_LNW), c.wp(MARL_P_CRI_LNB),
+                                c.at(c.e.AC1), d.ld_nla, c.at(c.e.STC1), rows, d.nla, st));
+    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZQ1), d.ld_nlb, c.wp(MARL_P_PRE_LNW), c.wp(MARL_P_PRE_LNB),
+                                c.at(c.e.AQ1), d.ld_nlb, c.at(c.e.STQ1), rows, d.nlb, st));
+    MARL_TRY(launch_rowdot(c.at(c.e.AC1), d.ld_nla, c.wp(MARL_P_CRI_W1), c.wp(MARL_P_CRI_B1),
+                           values, rows, d.nla, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AQ1), d.ld_nlb, c.wp(MARL_P_PRE_W1), d.ld_nlb, d.nlb,
+                                preds, d.nC, (int)rows, d.nC, c.wp(MARL_P_PRE_B1))));
+    return MARL_OK;
+}
+
+static void fill_sample_args(const Ctx& c, const marl_config* cfg, int t, SampleArgs& a) {
+    const Dims& d = c.d;
+    memset(&a, 0, sizeof(a));
+    a.a_pol = c.at(c.e.AP1, t);
+    a.ld_a = d.ld_nla;
+    a.nla = d.nla;
+    a.w1 = c.wp(MARL_P_POL_W1);
+    a.ldw = d.ld_nla;
+    a.b1 = c.wp(MARL_P_POL_B1);
+    a.pos_in = c.POSs(t);
+    a.pos_out = c.POSs(t + 1);
+    a.probs = c.PROBSs(t);
+    a.actions_i32 = c.ACTs(t);
+    a.R = (int)d.R;
+    a.nA = d.nA;
+    a.H = d.H;
+    a.W = d.W;
+    a.f = d.f;
+    for (int j = 0; j < d.nA; ++j) {
+        a.table[j][0] = cfg->actions[j][0];
+        a.table[j][1] = cfg->actions[j][1];
+    }
+}
+
+static int load_state(const Ctx& c, const float* h, const float* cc_, const float* hc,
+                      const float* cca, const float* msg) {
+    const Dims& d = c.d;
+    MARL_TRY(launch_copy2d(h, d.n_b, c.Hs(0), d.ld_nb, d.R, d.n_b, c.st));
+    MARL_TRY(launch_copy2d(cc_, d.n_b, c.Cs(0), d.ld_nb, d.R, d.n_b, c.st));
+    MARL_TRY(launch_copy2d(hc, d.n_a, c.HCs(0), d.ld_na, d.R, d.n_a, c.st));
+    MARL_TRY(launch_copy2d(cca, d.n_a, c.CCs(0), d.ld_na, d.R, d.n_a, c.st));
+    if (msg)
+        MARL_TRY(launch_copy2d(msg, d.n_m, c.MSGs(0), d.ld_nm, d.R, d.n_m, c.st));
+    else
+        MARL_TRY(launch_fill(c.MSGs(0), d.R * d.ld_nm, 0.f, c.st));  // models.py:161-162
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pack / unpack
+// ---------------------------------------------------------------------------
+struct PermQueue {
+    PermBatch b{};
+    hipStream_t st;
+    int rc = MARL_OK;
+    explicit PermQueue(hipStream_t s) : st(s) { b.count = 0; }
+    void push(const PermDesc& p) {
+        if (rc != MARL_OK) return;
+        b.d[b.count++] = p;
+        if (b.count == kMaxPerm) flush();
+    }
+    void flush() {
+        if (rc == MARL_OK && b.count > 0) rc = launch_permute(b, st);
+        b.count = 0;
+    }
+};
+
+static PermDesc perm(const float* src, float* dst, int rows, int cols, int dst_ld, int rd, int rs1,
+                     int rs2, int cd, int cs1, int cs2, const float* src2 = nullptr) {
+    PermDesc p;
+    p.src = src;
+    p.dst = dst;
+    p.rows = rows;
+    p.cols = cols;
+    p.dst_ld = dst_ld;
+    p.rd = rd;
+    p.rs1 = rs1;
+    p.rs2 = rs2;
+    p.cd = cd;
+    p.cs1 = cs1;
+    p.cs2 = cs2;
+    p.src2 = src2;
+    return p;
+}
+
+static int pack_weights(const Dims& d, const WLayout& w, const float* const* params, float* W,
+                        hipStream_t st) {
+    PermQueue q(st);
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        if (m.kind == PK_NONE) continue;
+        const float* src = params[i];
+        if (!src) {
+            set_error("parameter %d is null", i);
+            return MARL_EINVAL;
+        }
+        if (m.kind == PK_MATRIX) {
+            q.push(perm(src, W + w.wp[i], m.n, m.k, w.ldp[i], 1, m.k, 0, 1, 1, 0));
+            q.push(perm(src, W + w.wt[i], m.k, m.n, w.ldt[i], 1, 1, 0, 1, m.k, 0));
+        } else if (m.kind == PK_CONV) {
+            const int ci = m.k / 9;
+            // packed [co][tap*ci + c]  <- src [co][c][tap]
+            q.push(perm(src, W + w.wp[i], m.n, m.k, w.ldp[i], 1, m.k, 0, ci, 1, 9));
+            // transposed [tap*ci + c][co]
+            q.push(perm(src, W + w.wt[i], m.k, m.n, w.ldt[i], ci, 1, 9, 1, m.k, 0));
+        } else {
+            q.push(perm(src, W + w.wp[i], 1, m.n, m.n, 1, 0, 0, 1, 1, 0));
+        }
+    }
+    q.push(perm(params[MARL_P_LB_BIH], W + w.bsum_b, 1, 4 * d.n_b, 4 * d.n_b, 1, 0, 0, 1, 1, 0,
+                params[MARL_P_LB_BHH]));
+    q.push(perm(params[MARL_P_LA_BIH], W + w.bsum_a, 1, 4 * d.n_a, 4 * d.n_a, 1, 0, 0, 1, 1, 0,
+                params[MARL_P_LA_BHH]));
+    q.flush();
+    return q.rc;
+}
+
+static int unpack_grads(const Ctx& c, float* const* grads) {
+    PermQueue q(c.st);
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(c.d, i);
+        if (m.kind == PK_MATRIX) {
+            q.push(perm(c.gp(i), grads[i], m.n, m.k, m.k, 1, c.w.ldp[i], 0, 1, 1, 0));
+        } else if (m.kind == PK_CONV) {
+            const int ci = m.k / 9;
+            // dst [co][c*9 + tap] <- packed [co][tap*ci + c]
+            q.push(perm(c.gp(i), grads[i], m.n, m.k, m.k, 1, c.w.ldp[i], 0, 9, 1, ci));
+        }
+    }
+    q.flush();
+    return q.rc;
+}
+
+// ---------------------------------------------------------------------------
+// backward helpers
+// ---------------------------------------------------------------------------
+static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, int pidx, int ni,
+              int nj, int64_t rows) {
+    return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
+                          c.e.tns_bytes, c.st);
+}
+static int csum(const Ctx& c, const float* x, int ld, int64_t rows, int n, float* out) {
+    return launch_colsum(x, ld, rows, n, out, c.at(c.e.CSUM), c.st);
+}
+// LayerNorm+SiLU backward in place (da -> dz) with affine gradients (accumulated when acc)
+static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, const float* stats,
+                  int pw, int pb, int64_t rows, int n, float* const* grads, int acc,
+                  float* dz = nullptr, int lddz = 0) {
+    if (!dz) {
+        dz = da;
+        lddz = ldda;
+    }
+    MARL_TRY(launch_ln_silu_bwd(da, ldda, z, ldz, stats, c.wp(pw), c.wp(pb), dz, lddz,
+                                c.at(c.e.PART), rows, n, c.st));
+    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows), n, grads[pw], grads[pb], acc,
+                                c.st);
+}
+
+static int episode_backward(const Ctx& c, const float* g_preds, const float* g_logp,
+                            const float* g_values, float* const* grads) {
+    const Dims& d = c.d;
+    hipStream_t st = c.st;
+    const int64_t NR = d.NR;
+    const int R = (int)d.R, ns = d.ns;
+    for (int i = 0; i < MARL_NPARAMS; ++i)
+        if (param_meta(d, i).kind != PK_NONE && !grads[i]) {
+            set_error("gradient buffer %d is null", i);
+            return MARL_EINVAL;
+        }
+    // ---- heads, batched over all steps -----------------------------------------------
+    // prediction head (networks/prediction.py:11-14)
+    if (g_preds)
+        MARL_TRY(launch_copy2d(g_preds, d.nC, c.at(c.e.GPRED), d.ld_nC, NR, d.nC, st));
+    else
+        MARL_TRY(launch_fill(c.at(c.e.GPRED), NR * d.ld_nC, 0.f, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.GPRED), d.ld_nC, c.wt(MARL_P_PRE_W1), p4(d.nC), d.nC,
+                                c.at(c.e.DAQ1), d.ld_nlb, (int)NR, d.nlb)));
+    MARL_TRY(tn(c, c.at(c.e.GPRED), d.ld_nC, c.at(c.e.AQ1), d.ld_nlb, MARL_P_PRE_W1, d.nC, d.nlb, NR));
+    MARL_TRY(csum(c, c.at(c.e.GPRED), d.ld_nC, NR, d.nC, grads[MARL_P_PRE_B1]));
+    MARL_TRY(ln_bwd(c, c.at(c.e.DAQ1), d.ld_nlb, c.at(c.e.ZQ1), d.ld_nlb, c.at(c.e.STQ1),
+                    MARL_P_PRE_LNW, MARL_P_PRE_LNB, NR, d.nlb, grads, 0));
+    MARL_TRY(tn(c, c.at(c.e.DAQ1), d.ld_nlb, c.Hs(1), d.ld_nb, MARL_P_PRE_W0, d.nlb, d.n_b, NR));
+    MARL_TRY(csum(c, c.at(c.e.DAQ1), d.ld_nlb, NR, d.nlb, grads[MARL_P_PRE_B0]));
+    // critic head (networks/policy.py:23-27)
+    if (g_values)
+        MARL_TRY(launch_copy2d(g_values, 1, c.at(c.e.DVAL), 4, NR, 1, st));
+    else
+        MARL_TRY(launch_fill(c.at(c.e.DVAL), NR * 4, 0.f, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DVAL), 4, c.wt(MARL_P_CRI_W1), 4, 1, c.at(c.e.DAC1),
+                                d.ld_nla, (int)NR, d.nla)));
+    MARL_TRY(tn(c, c.at(c.e.DVAL), 4, c.at(c.e.AC1), d.ld_nla, MARL_P_CRI_W1, 1, d.nla, NR));
+    MARL_TRY(csum(c, c.at(c.e.DVAL), 4, NR, 1, grads[MARL_P_CRI_B1]));
+    MARL_TRY(ln_bwd(c, c.at(c.e.DAC1), d.ld_nla, c.at(c.e.ZC1), d.ld_nla, c.at(c.e.STC1),
+                    MARL_P_CRI_LNW, MARL_P_CRI_LNB, NR, d.nla, grads, 0));
+    MARL_TRY(tn(c, c.at(c.e.DAC1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_CRI_W0, d.nla, d.n_a, NR));
+    MARL_TRY(csum(c, c.at(c.e.DAC1), d.ld_nla, NR, d.nla, grads[MARL_P_CRI_B0]));
+    // policy head: logp = log softmax(logits)[a]  (networks/policy.py:12-16, core/agent.py:57-61)
+    MARL_TRY(launch_policy_dlogits(g_logp, c.PROBSs(0), c.ACTs(0), c.at(c.e.DLOG), d.ld_nA, NR,
+                                   d.nA, st));
+    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DLOG), d.ld_nA, c.wt(MARL_P_POL_W1), p4(d.nA), d.nA,
+                                c.at(c.e.DAP1), d.ld_nla, (int)NR, d.nla)));
+    MARL_TRY(tn(c, c.at(c.e.DLOG), d.ld_nA, c.at(c.e.AP1, 0), d.ld_nla, MARL_P_POL_W1, d.nA, d.nla, NR));
+    MARL_TRY(csum(c, c.at(c.e.DLOG), d.ld_nA, NR, d.nA, grads[MARL_P_POL_B1]));
+    MARL_TRY(ln_bwd(c, c.at(c.e.DAP1), d.ld_nla, c.at(c.e.ZP1, 0), d.ld_nla, c.at(c.e.STP1, 0),
+                    MARL_P_POL_LNW, MARL_P_POL_LNB, NR, d.nla, grads, 0));
+    MARL_TRY(tn(c, c.at(c.e.DAP1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_POL_W0, d.nla, d.n_a, NR));
+    MARL_TRY(csum(c, c.at(c.e.DAP1), d.ld_nla, NR, d.nla, grads[MARL_P_POL_B0]));
+    // gradients reaching h_t / h^_t from the heads, all steps at once
+    {
+        GemmProb ph = gemm_prob(c.at(c.e.DAQ1), d.ld_nlb, c.wt(MARL_P_PRE_W0), d.ld_nlb, d.nlb,
+                                c.DHs(1), d.ld_nb, (int)NR, d.n_b);
+        GemmProb pa = gemm_prob(c.at(c.e.DAP1), d.ld_nla, c.wt(MARL_P_POL_W0), d.ld_nla, d.nla,
+                                c.DHCs(1), d.ld_na, (int)NR, d.n_a);
+        gemm_add_seg(pa, c.at(c.e.DAC1), d.ld_nla, c.wt(MARL_P_CRI_W0), d.ld_nla, d.nla);
+        MARL_TRY(gemm2(c, ph, pa));
+    }
+    MARL_TRY(launch_fill(c.DHs(0), d.R * d.ld_nb, 0.f, st));
+    MARL_TRY(launch_fill(c.DHCs(0), d.R * d.ld_na, 0.f, st));
+    MARL_TRY(launch_fill(c.at(c.e.DC), d.R * d.ld_nb, 0.f, st));
+    MARL_TRY(launch_fill(c.at(c.e.DCC), d.R * d.ld_na, 0.f, st));
+
+    // ---- reverse-time loop over the recurrent chain ----------------------------------
+    const size_t s_nmo = (size_t)d.R * d.ld_nmo, s_nm2 = (size_t)d.R * d.ld_nm2,
+                 s_nm = (size_t)d.R * d.ld_nm;
+    for (int t = ns - 1; t >= 0; --t) {
+        const int first = (t == ns - 1);
+        MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
+                                      d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.R, d.n_b, st));
+        MARL_TRY(launch_lstm_cell_bwd(c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
+                                      c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1), d.ld_na, d.R,
+                                      d.n_a, st));
+        // recurrent paths: dh_{t-1} += dgates * W_hh
+        MARL_TRY(gemm2(c,
+                       gemm_prob(c.at(c.e.GB, t), d.ld_gb, c.wt(MARL_P_LB_WHH), d.ld_gb, 4 * d.n_b,
+                                 c.DHs(t), d.ld_nb, R, d.n_b, nullptr, 1),
+                       gemm_prob(c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WHH), d.ld_ga, 4 * d.n_a,
+                                 c.DHCs(t), d.ld_na, R, d.n_a, nullptr, 1)));
+        // d(decoded message) = columns [nf, nf + n_mo) of dU
+        float* ddbar = c.at(c.e.DDBAR) + (size_t)t * s_nmo;
+        {
+            GemmProb p = gemm_prob(c.at(c.e.GB, t), d.ld_gb,
+                                   c.wt(MARL_P_LB_WIH) + (size_t)d.nf * d.ld_gb, d.ld_gb, 4 * d.n_b,
+                                   ddbar, d.ld_nmo, R, d.n_mo);
+            gemm_add_seg(p, c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga,
+                         d.ld_ga, 4 * d.n_a);
+            MARL_TRY(gemm1(c, p));
+        }
+        MARL_TRY(ln_bwd(c, ddbar, d.ld_nmo, c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
+                        MARL_P_DEC_LN1W, MARL_P_DEC_LN1B, d.R, d.n_mo, grads, !first));
+        float* dad1 = c.at(c.e.DAD1) + (size_t)t * s_nm2;
+        MARL_TRY(gemm1(c, gemm_prob(ddbar, d.ld_nmo, c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.n_mo, dad1,
+                                    d.ld_nm2, R, d.nm2)));
+        MARL_TRY(ln_bwd(c, dad1, d.ld_nm2, c.at(c.e.ZD1, t), d.ld_nm2, c.at(c.e.STD1, t),
+                        MARL_P_DEC_LN0W, MARL_P_DEC_LN0B, d.R, d.nm2, grads, !first));
+        if (t > 0) {
+            // through the message mean (self-adjoint) into the encoder of step t-1
+            MARL_TRY(gemm1(c, gemm_prob(dad1, d.ld_nm2, c.wt(MARL_P_DEC_W0), p4(d.nm2), d.nm2,
+                                        c.at(c.e.DMBAR), d.ld_nm, R, d.n_m)));
+            float* dze2 = c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm;
+            MARL_TRY(launch_agg_msg(c.at(c.e.DMBAR), dze2, d.ld_nm, d.na, d.nb, d.n_m, st));
+            const int efirst = (t == ns - 1);
+            MARL_TRY(ln_bwd(c, dze2, d.ld_nm, c.at(c.e.ZE2, t - 1), d.ld_nm, c.at(c.e.STE2, t - 1),
+                            MARL_P_ENC_LN1W, MARL_P_ENC_LN1B, d.R, d.n_m, grads, !efirst));
+            float* dae1 = c.at(c.e.DAE1) + (size_t)(t - 1) * s_nm2;
+            MARL_TRY(gemm1(c, gemm_prob(dze2, d.ld_nm, c.wt(MARL_P_ENC_W1), p4(d.n_m), d.n_m, dae1,
+                                        d.ld_nm2, R, d.nm2)));
+            MARL_TRY(ln_bwd(c, dae1, d.ld_nm2, c.at(c.e.ZE1, t - 1), d.ld_nm2,
+                            c.at(c.e.STE1, t - 1), MARL_P_ENC_LN0W, MARL_P_ENC_LN0B, d.R, d.nm2,
+                            grads, !efirst));
+            MARL_TRY(gemm1(c, gemm_prob(dae1, d.ld_nm2, c.wt(MARL_P_ENC_W0), p4(d.nm2), d.nm2,
+                                        c.DHs(t), d.ld_nb, R, d.n_b, nullptr, 1)));
+        }
+    }
+
+    // ---- weight gradients of the recurrent chain: one contraction over all steps -------
+    MARL_TRY(tn(c, c.at(c.e.DDBAR), d.ld_nmo, c.at(c.e.AD1, 0), d.ld_nm2, MARL_P_DEC_W1, d.n_mo, d.nm2, NR));
+    MARL_TRY(csum(c, c.at(c.e.DDBAR), d.ld_nmo, NR, d.n_mo, grads[MARL_P_DEC_B1]));
+    MARL_TRY(tn(c, c.at(c.e.DAD1), d.ld_nm2, c.at(c.e.MBAR, 0), d.ld_nm, MARL_P_DEC_W0, d.nm2, d.n_m, NR));
+    MARL_TRY(csum(c, c.at(c.e.DAD1), d.ld_nm2, NR, d.nm2, grads[MARL_P_DEC_B0]));
+    if (ns > 1) {
+        const int64_t er = (int64_t)(ns - 1) * d.R;  // the last step's message is never read
+        MARL_TRY(tn(c, c.at(c.e.DZE2), d.ld_nm, c.at(c.e.AE1, 0), d.ld_nm2, MARL_P_ENC_W1, d.n_m, d.nm2, er));
+        MARL_TRY(csum(c, c.at(c.e.DZE2), d.ld_nm, er, d.n_m, grads[MARL_P_ENC_B1]));
+        MARL_TRY(tn(c, c.at(c.e.DAE1), d.ld_nm2, c.Hs(1), d.ld_nb, MARL_P_ENC_W0, d.nm2, d.n_b, er));
+        MARL_TRY(csum(c, c.at(c.e.DAE1), d.ld_nm2, er, d.nm2, grads[MARL_P_ENC_B0]));
+    } else {
+        const int enc[] = {MARL_P_ENC_B0, MARL_P_ENC_LN0W, MARL_P_ENC_LN0B, MARL_P_ENC_B1,
+                           MARL_P_ENC_LN1W, MARL_P_ENC_LN1B};
+        for (int i : enc) MARL_TRY(launch_fill(grads[i], param_meta(d, i).n, 0.f, st));
+        MARL_TRY(launch_fill(c.gp(MARL_P_ENC_W0), (int64_t)d.nm2 * c.w.ldp[MARL_P_ENC_W0], 0.f, st));
+        MARL_TRY(launch_fill(c.gp(MARL_P_ENC_W1), (int64_t)d.n_m * c.w.ldp[MARL_P_ENC_W1], 0.f, st));
+    }
+    MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.at(c.e.U, 0), d.ld_nin, MARL_P_LB_WIH, 4 * d.n_b, d.nin, NR));
+    MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR));
+    MARL_TRY(csum(c, c.at(c.e.GB, 0), d.ld_gb, NR, 4 * d.n_b, grads[MARL_P_LB_BIH]));
+    MARL_TRY(launch_copy2d(grads[MARL_P_LB_BIH], 0, grads[MARL_P_LB_BHH], 0, 1, 4 * d.n_b, st));
+    MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.at(c.e.U, 0), d.ld_nin, MARL_P_LA_WIH, 4 * d.n_a, d.nin, NR));
+    MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.HCs(0), d.ld_na, MARL_P_LA_WHH, 4 * d.n_a, d.n_a, NR));
+    MARL_TRY(csum(c, c.at(c.e.GA, 0), d.ld_ga, NR, 4 * d.n_a, grads[MARL_P_LA_BIH]));
+    MARL_TRY(launch_copy2d(grads[MARL_P_LA_BIH], 0, grads[MARL_P_LA_BHH], 0, 1, 4 * d.n_a, st));
+
+    // ---- dU for all steps, then position embedding and CNN backward -------------------
+    {
+        GemmProb p = gemm_prob(c.at(c.e.GB, 0), d.ld_gb, c.wt(MARL_P_LB_WIH), d.ld_gb, 4 * d.n_b,
+                               c.at(c.e.DU), d.ld_nin, (int)NR, d.nin);
+        gemm_add_seg(p, c.at(c.e.GA, 0), d.ld_ga, c.wt(MARL_P_LA_WIH), d.ld_ga, 4 * d.n_a);
+        MARL_TRY(gemm1(c, p));
+    }
+    MARL_TRY(ln_bwd(c, c.at(c.e.DU) + d.nf + d.n_mo, d.ld_nin, c.at(c.e.ZPOS, 0), d.ld_nd,
+                    c.at(c.e.STPOS, 0), MARL_P_POS_LNW, MARL_P_POS_LNB, NR, d.n_d, grads, 0,
+                    c.at(c.e.DZPOS), d.ld_nd));
+    MARL_TRY(tn(c, c.at(c.e.DZPOS), d.ld_nd, c.at(c.e.NPOS, 0), 4, MARL_P_POS_W, d.n_d, 2, NR));
+    MARL_TRY(csum(c, c.at(c.e.DZPOS), d.ld_nd, NR, d.n_d, grads[MARL_P_POS_B]));
+    {
+        const float* da = c.at(c.e.DU);
+        int64_t ldda = d.ld_nin;
+        int chw = 1;
+        for (int l = d.L - 1; l >= 0; --l) {
+            const int co = d.ch[l + 1];
+            const int64_t rows = NR * d.P[l];
+            float* dz = c.at(c.e.DZ[l]);
+            MARL_TRY(launch_gn_silu_bwd(da, ldda, chw, c.at(c.e.Z[l], 0), c.at(c.e.GST[l], 0),
+                                        c.wp(4 * l + 2), c.wp(4 * l + 3), dz, c.at(c.e.PART), NR,
+                                        d.P[l], co, d.grp[l], st));
+            MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR), co, grads[4 * l + 2],
+                                          grads[4 * l + 3], 0, st));
+            MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows));
+            MARL_TRY(csum(c, dz, co, rows, co, grads[4 * l + 1]));
+            if (l > 0) {
+                MARL_TRY(gemm1(c, gemm_prob(dz, co, c.wt(4 * l), p4(co), co, c.at(c.e.DCOLS[l]),
+                                            d.ldk[l], (int)rows, d.K[l])));
+                MARL_TRY(launch_col2im(c.at(c.e.DCOLS[l]), d.ldk[l], c.at(c.e.DA[l - 1]), NR,
+                                       d.hw[l], d.ch[l], st));
+                da = c.at(c.e.DA[l - 1]);
+                ldda = (int64_t)d.P[l - 1] * d.ch[l];
+                chw = 0;
+            }
+        }
+    }
+    return unpack_grads(c, grads);
+}
+
+}  // namespace marl
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace marl;
+
+extern "C" {
+
+int marl_abi_version(void) { return MARL_ABI_VERSION; }
+
+int64_t marl_param_numel(const marl_config* cfg, int index) {
+    Dims d;
+    if (make_dims(cfg, d) != MARL_OK || index < 0 || index >= MARL_NPARAMS) return -1;
+    const ParamMeta m = param_meta(d, index);
+    if (m.kind == PK_NONE) return 0;
+    return m.kind == PK_VEC ? m.n : (int64_t)m.n * m.k;
+}
+
+int marl_workspace_sizes(const marl_config* cfg, int train, size_t* wbytes, size_t* ebytes) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    WLayout w;
+    make_wlayout(d, w);
+    ELayout e;
+    make_elayout(d, train, e);
+    if (wbytes) *wbytes = w.total * sizeof(float);
+    if (ebytes) *ebytes = e.total * sizeof(float);
+    return MARL_OK;
+}
+
+int marl_pack_weights(const marl_config* cfg, const float* const* params_host, void* weights_ws,
+                      void* stream) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    if (!params_host || !weights_ws) {
+        set_error("null argument");
+        return MARL_EINVAL;
+    }
+    WLayout w;
+    make_wlayout(d, w);
+    return pack_weights(d, w, params_host, static_cast<float*>(weights_ws),
+                        static_cast<hipStream_t>(stream));
+}
+
+int marl_patch_gather(const float* img, const int64_t* pos, float* obs, int nb_agents, int batch,
+                      int c, int h, int w, int f, void* stream) {
+    if (!img || !pos || !obs || nb_agents < 1 || batch < 1 || c < 1 || f < 1 || h < f || w < f) {
+        set_error("patch_gather: bad argument");
+        return MARL_EINVAL;
+    }
+    return launch_patch_gather(img, pos, obs, nb_agents, batch, c, h, w, f,
+                               static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+namespace marl {
+__global__ void transition_kernel(const int64_t* __restrict__ pos_in,
+                                  const int64_t* __restrict__ actions,
+                                  int64_t* __restrict__ pos_out, SampleArgs tbl, int rows, int nA,
+                                  int H, int W, int f) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int a = (int)actions[r];
+    a = a < 0 ? 0 : (a >= nA ? nA - 1 : a);
+    const int64_t p0 = pos_in[r * 2], p1 = pos_in[r * 2 + 1];
+    const int64_t q0 = p0 + tbl.table[a][0], q1 = p1 + tbl.table[a][1];
+    const bool ok = q0 >= 0 && q0 + f < H && q1 >= 0 && q1 + f < W;
+    pos_out[r * 2] = ok ? q0 : p0;
+    pos_out[r * 2 + 1] = ok ? q1 : p1;
+}
+}  // namespace marl
+
+extern "C" {
+
+int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_out,
+                    const int32_t* table_host, int nb_action, int rows, int h, int w, int f,
+                    void* stream) {
+    if (!pos_in || !actions || !pos_out || !table_host || nb_action < 1 ||
+        nb_action > MARL_MAX_ACTIONS || rows < 1) {
+        set_error("transition: bad argument");
+        return MARL_EINVAL;
+    }
+    SampleArgs tbl;
+    memset(&tbl, 0, sizeof(tbl));
+    for (int j = 0; j < nb_action; ++j) {
+        tbl.table[j][0] = table_host[2 * j];
+        tbl.table[j][1] = table_host[2 * j + 1];
+    }
+    hipLaunchKernelGGL(transition_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pos_in, actions, pos_out, tbl, rows,
+                       nb_action, h, w, f);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+                         const float* img, const int64_t* pos0, const float* h0, const float* c0,
+                         const float* hc0, const float* cc0, const float* noise,
+                         const int64_t* forced_actions, float* step_preds, float* step_logp,
+                         float* step_values, int64_t* step_pos, int64_t* step_actions, int train,
+                         void* stream) {
+    Ctx c;
+    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, train, stream, c));
+    if (!img || !pos0 || !h0 || !c0 || !hc0 || !cc0 || (!noise && !forced_actions) || !step_preds ||
+        !step_logp || !step_values) {
+        set_error("episode_forward: null argument");
+        return MARL_EINVAL;
+    }
+    const Dims& d = c.d;
+    MARL_TRY(launch_i64_to_i32(pos0, c.POSs(0), d.R * 2, c.st));
+    MARL_TRY(load_state(c, h0, c0, hc0, cc0, nullptr));
+    StepIn in;
+    in.img = img;
+    for (int t = 0; t < d.ns; ++t) {
+        MARL_TRY(step_core(c, t, in));
+        SampleArgs a;
+        fill_sample_args(c, cfg, t, a);
+        a.noise = noise ? noise + (size_t)t * d.R * d.nA : nullptr;
+        a.forced = forced_actions ? forced_actions + (size_t)t * d.R : nullptr;
+        a.step_pos = step_pos ? step_pos + (size_t)t * d.R * 2 : nullptr;
+        a.step_actions = step_actions ? step_actions + (size_t)t * d.R : nullptr;
+        a.step_logp = step_logp + (size_t)t * d.R;
+        MARL_TRY(launch_sample(a, c.st));
+    }
+    return heads_batched(c, 0, d.NR, step_values, step_preds);
+}
+
+int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
+                          const float* g_preds, const float* g_logp, const float* g_values,
+                          float* const* grads_host, void* stream) {
+    Ctx c;
+    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 1, stream, c));
+    if (!grads_host) {
+        set_error("episode_backward: null gradient table");
+        return MARL_EINVAL;
+    }
+    return episode_backward(c, g_preds, g_logp, g_values, grads_host);
+}
+
+int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float* step_preds,
+                          const float* step_logp, const float* step_values, const int64_t* y,
+                          float gamma, float* g_preds, float* g_logp, float* g_values,
+                          float* scalars_out, double* adv_stats, int phase, void* stream) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    if (!episode_ws || !step_preds || !step_logp || !step_values || !y || !scalars_out ||
+        !adv_stats || phase < 0 || phase > 2) {
+        set_error("a2c_loss: bad argument");
+        return MARL_EINVAL;
+    }
+    // the loss scratch is the last buffer of either episode-workspace layout
+    ELayout e;
+    make_elayout(d, 1, e);
+    LossArgs a;
+    a.preds = step_preds;
+    a.logp = step_logp;
+    a.values = step_values;
+    a.y = y;
+    a.g_preds = g_preds;
+    a.ld_gp = d.nC;
+    a.g_logp = g_logp;
+    a.g_values = g_values;
+    a.scalars = scalars_out;
+    a.adv_stats = adv_stats;
+    a.scratch = static_cast<float*>(episode_ws) + e.LOSS;
+    a.ns = d.ns;
+    a.na = d.na;
+    a.nb = d.nb;
+    a.nc = d.nC;
+    a.gamma = gamma;
+    a.phase = phase;
+    return launch_loss(a, static_cast<hipStream_t>(stream));
+}
+
+int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) {
+        set_error("adam: bad argument");
+        return MARL_EINVAL;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, n, (float)((double)lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale,
+                       static_cast<hipStream_t>(stream));
+}
+
+int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+                      const float* obs, const float* msg, const float* norm_pos, const float* h,
+                      const float* cc_, const float* hc, const float* cca, float* probs,
+                      float* values, float* preds, float* new_msg, float* h_out, float* c_out,
+                      float* hc_out, float* cc_out, void* stream) {
+    Ctx c;
+    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 0, stream, c));
+    if (!obs || !msg || !norm_pos || !h || !cc_ || !hc || !cca || !probs || !values || !preds ||
+        !new_msg || !h_out || !c_out || !hc_out || !cc_out) {
+        set_error("step_forward: null argument");
+        return MARL_EINVAL;
+    }
+    const Dims& d = c.d;
+    MARL_TRY(load_state(c, h, cc_, hc, cca, msg));
+    StepIn in;
+    in.obs = obs;
+    in.npos = norm_pos;
+    MARL_TRY(step_core(c, 0, in));
+    SampleArgs a;
+    fill_sample_args(c, cfg, 0, a);
+    a.probs = probs;
+    a.step_logp = nullptr;  // probabilities only
+    MARL_TRY(launch_sample(a, c.st));
+    MARL_TRY(heads_batched(c, 0, d.R, values, preds));
+    MARL_TRY(launch_copy2d(c.MSGs(1), d.ld_nm, new_msg, d.n_m, d.R, d.n_m, c.st));
+    MARL_TRY(launch_copy2d(c.Hs(1), d.ld_nb, h_out, d.n_b, d.R, d.n_b, c.st));
+    MARL_TRY(launch_copy2d(c.Cs(1), d.ld_nb, c_out, d.n_b, d.R, d.n_b, c.st));
+    MARL_TRY(launch_copy2d(c.HCs(1), d.ld_na, hc_out, d.n_a, d.R, d.n_a, c.st));
+    MARL_TRY(launch_copy2d(c.CCs(1), d.ld_na, cc_out, d.n_a, d.R, d.n_a, c.st));
+    return MARL_OK;
+}
+
+// test hook: where a named activation of step t lives inside episode_ws (float offset, ld)
+int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t,
+                      int64_t* offset_floats, int* ld) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    ELayout e;
+    make_elayout(d, train, e);
+    if (!name || !offset_floats || !ld || t < 0 || t > d.ns) return MARL_EINVAL;
+    const size_t R = (size_t)d.R;
+    const int ts = train ? t : 0;
+    auto set = [&](size_t off, int l) {
+        *offset_floats = (int64_t)off;
+        *ld = l;
+        return MARL_OK;
+    };
+    if (!strcmp(name, "U")) return set(e.U.at(ts), d.ld_nin);
+    if (!strcmp(name, "H")) return set(e.H + (size_t)t * R * d.ld_nb, d.ld_nb);
+    if (!strcmp(name, "C")) return set(e.C + (size_t)t * R * d.ld_nb, d.ld_nb);
+    if (!strcmp(name, "HC")) return set(e.HC + (size_t)t * R * d.ld_na, d.ld_na);
+    if (!strcmp(name, "CC")) return set(e.CC + (size_t)t * R * d.ld_na, d.ld_na);
+    if (!strcmp(name, "MSG")) return set(e.MSG + (size_t)t * R * d.ld_nm, d.ld_nm);
+    if (!strcmp(name, "PROBS")) return set(e.PROBS + (size_t)t * R * d.nA, d.nA);
+    if (!strcmp(name, "COLS0")) return set(e.COLS[0].at(ts), d.ldk[0]);
+    if (!strcmp(name, "Z0")) return set(e.Z[0].at(ts), d.ch[1]);
+    if (!strcmp(name, "GB")) return set(e.GB.at(ts), d.ld_gb);
+    if (train) {
+        if (!strcmp(name, "DU")) return set(e.DU + (size_t)t * R * d.ld_nin, d.ld_nin);
+        if (!strcmp(name, "DH")) return set(e.DH + (size_t)t * R * d.ld_nb, d.ld_nb);
+        if (!strcmp(name, "DHC")) return set(e.DHC + (size_t)t * R * d.ld_na, d.ld_na);
+    }
+    set_error("unknown debug buffer %s", name);
+    return MARL_EINVAL;
+}
+
+// ---- kernel-level entry points -------------------------------------------------------
+int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* bias, float* c,
+                 int ldc, int m, int n, int k, int accumulate, void* stream) {
+    GemmBatch bt{};
+    bt.p[0] = gemm_prob(a, lda, b, ldb, k, c, ldc, m, n, bias, accumulate);
+    bt.count = 1;
+    return launch_gemm_nt(bt, static_cast<hipStream_t>(stream));
+}
+
+size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows) { return gemm_tn_scratch_bytes(ni, nj, rows); }
+
+int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni, int nj,
+                 int64_t rows, float* scratch, size_t scratch_bytes, void* stream) {
+    return launch_gemm_tn(a, lda, b, ldb, c, ldc, ni, nj, rows, scratch, scratch_bytes,
+                          static_cast<hipStream_t>(stream));
+}
+
+int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
+                     int ldo, float* stats, int m, int n, void* stream) {
+    return launch_ln_silu_fwd(z, ldz, gamma, beta, out, ldo, stats, m, n,
+                              static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,481 @@
+// fp32 matrix kernels on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bitwise an fmaf chain, 157 TF peak - MI355X_MICROARCH.md).
+//
+//  gemm_nt_kernel : C[M,N] (+)= sum_s A_s[M,K_s] * B_s[N,K_s]^T + bias   (activations x weights)
+//                   optional fused LSTM-cell epilogue (networks/recurrent.py:19-35)
+//  gemm_tn_kernel : C[NI,NJ] = sum_r A[r,i] * B[r,j]                      (weight gradients)
+//
+// Tiling is for 64-lane waves: a 256-thread workgroup = 4 waves, each wave owns
+// TM x TN accumulator tiles of 32x32 (16 VGPRs each).  Operand tiles are staged
+// global -> registers -> LDS (double buffered, one barrier per K tile); LDS rows are
+// padded to 20 floats so that the ds_read_b128 fragment reads are bank-conflict free.
+#include "common.h"
+
+namespace marl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;          // K depth of one staged tile
+constexpr int LDS_K = BK + 4;   // padded LDS row stride (floats) for K-contiguous tiles
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// accurate variants used where the result feeds saved state (error ~1 ulp)
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BM, int BN, int WM, int WN, bool LSTM>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_CH = BM * (BK / 4) / 256;
+    constexpr int B_CH = BN * (BK / 4) / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+    static_assert(!LSTM || (WN == 1 && BN == 128), "LSTM tile = 4 gates x 32 units");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_K];
+
+    const GemmProb& P = batch.p[blockIdx.z];
+    const int M = P.m;
+    const int N = P.n;  // LSTM: number of hidden units (B has 4*N rows)
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * (LSTM ? 32 : BN);
+    if (m0 >= M || n0 >= N) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int t0 = (P.seg[0].k + BK - 1) / BK;
+    const int t1 = P.nseg > 1 ? (P.seg[1].k + BK - 1) / BK : 0;
+    const int T = t0 + t1;
+
+    float4 ra[A_CH], rb[B_CH];
+
+    auto load_tile = [&](int tile) {
+        const bool s1 = tile >= t0;
+        const float* __restrict__ ga = s1 ? P.seg[1].a : P.seg[0].a;
+        const float* __restrict__ gb = s1 ? P.seg[1].b : P.seg[0].b;
+        const int lda = s1 ? P.seg[1].lda : P.seg[0].lda;
+        const int ldb = s1 ? P.seg[1].ldb : P.seg[0].ldb;
+        const int K4 = ((s1 ? P.seg[1].k : P.seg[0].k) + 3) & ~3;
+        const int k0 = (s1 ? tile - t0 : tile) * BK;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 2;
+            const int k = k0 + (c & 3) * 4;
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            ra[i] = (k < K4) ? *reinterpret_cast<const float4*>(ga + (size_t)gm * lda + k)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 2;
+            const int k = k0 + (c & 3) * 4;
+            int gn;
+            if (LSTM) {
+                int unit = n0 + (row & 31);
+                unit = unit < N ? unit : N - 1;
+                gn = (row >> 5) * N + unit;
+            } else {
+                gn = n0 + row;
+                gn = gn < N ? gn : N - 1;
+            }
+            rb[i] = (k < K4) ? *reinterpret_cast<const float4*>(gb + (size_t)gn * ldb + k)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * (BM + BN) * LDS_K;
+        float* Bs = As + BM * LDS_K;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<float4*>(As + (c >> 2) * LDS_K + (c & 3) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<float4*>(Bs + (c >> 2) * LDS_K + (c & 3) * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+
+    for (int tile = 0; tile < T; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < T) load_tile(tile + 1);
+
+        const float* As = smem + buf * (BM + BN) * LDS_K + (wm * (BM / WM) + frag_row) * LDS_K + frag_k;
+        const float* Bs = smem + buf * (BM + BN) * LDS_K + BM * LDS_K +
+                          (wn * (BN / WN) + frag_row) * LDS_K + frag_k;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_K + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (tile + 1 < T) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] is C[row(r), col], col = lane & 31,
+    //      row(r) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    if (!LSTM) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / WN) + j * 32 + col_l;
+                if (col >= N) continue;
+                const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                    if (row < M) {
+                        float* cp = P.c + (size_t)row * P.ldc + col;
+                        float v = acc[i][j][r] + bv;
+                        if (P.accumulate) v += *cp;
+                        *cp = v;
+                    }
+                }
+            }
+    } else {
+        const int unit = n0 + col_l;
+        if (unit < N) {
+            const float bi = P.bias[unit], bf = P.bias[N + unit], bg = P.bias[2 * N + unit],
+                        bo = P.bias[3 * N + unit];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                if (row < M) {
+                    const float gi = sigmoid_acc(acc[0][0][r] + bi);
+                    const float gf = sigmoid_acc(acc[0][1][r] + bf);
+                    const float gg = tanhf(acc[0][2][r] + bg);
+                    const float go = sigmoid_acc(acc[0][3][r] + bo);
+                    const size_t so = (size_t)row * P.ld_state + unit;
+                    const float cn = gf * P.c_prev[so] + gi * gg;
+                    P.c_next[so] = cn;
+                    P.h_next[so] = go * tanhf(cn);
+                    if (P.gates) {
+                        float* gp = P.gates + (size_t)row * P.ld_gates + unit;
+                        gp[0] = gi;
+                        gp[N] = gf;
+                        gp[2 * N] = gg;
+                        gp[3 * N] = go;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// TN: contraction over rows.  LDS tiles are [BK rows][BM or BN columns]; the MFMA
+// fragments are ds_read_b32 with consecutive lanes on consecutive columns.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb,
+                                                      float* __restrict__ out, int ldo,
+                                                      int64_t out_split_stride, int NI, int NJ,
+                                                      int64_t rows, int64_t rows_per_split) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_CH = BK * (BM / 4) / 256;
+    constexpr int B_CH = BK * (BN / 4) / 256;
+    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+
+    const int i0 = blockIdx.x * BM;
+    const int j0 = blockIdx.y * BN;
+    const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+    int64_t r_end = r_begin + rows_per_split;
+    if (r_end > rows) r_end = rows;
+    const int NI4 = (NI + 3) & ~3, NJ4 = (NJ + 3) & ~3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int T = r_end > r_begin ? (int)((r_end - r_begin + BK - 1) / BK) : 0;
+
+    float4 ra[A_CH], rb[B_CH];
+    auto load_tile = [&](int tile) {
+        const int64_t rb0 = r_begin + (int64_t)tile * BK;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int kr = c / (BM / 4);
+            const int ic = (c % (BM / 4)) * 4;
+            const int64_t gr = rb0 + kr;
+            ra[i] = (gr < r_end && i0 + ic < NI4)
+                        ? *reinterpret_cast<const float4*>(A + (size_t)gr * lda + i0 + ic)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int c = tid + 256 * i;
+            const int kr = c / (BN / 4);
+            const int jc = (c % (BN / 4)) * 4;
+            const int64_t gr = rb0 + kr;
+            rb[i] = (gr < r_end && j0 + jc < NJ4)
+                        ? *reinterpret_cast<const float4*>(B + (size_t)gr * ldb + j0 + jc)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * BK * (BM + BN);
+        float* Bs = As + BK * BM;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<float4*>(As + (c / (BM / 4)) * BM + (c % (BM / 4)) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<float4*>(Bs + (c / (BN / 4)) * BN + (c % (BN / 4)) * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (T > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int fcol = lane & 31;
+    const int fk = lane >> 5;
+    for (int tile = 0; tile < T; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < T) load_tile(tile + 1);
+        const float* As = smem + buf * BK * (BM + BN) + wm * (BM / WM) + fcol;
+        const float* Bs = smem + buf * BK * (BM + BN) + BK * BM + wn * (BN / WN) + fcol;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(ks * 2 + fk) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(ks * 2 + fk) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (tile + 1 < T) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* o = out + (size_t)blockIdx.z * out_split_stride;
+    const int row_h = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = j0 + wn * (BN / WN) + j * 32 + fcol;
+            if (col >= NJ) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                if (row < NI) o[(size_t)row * ldo + col] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int64_t split_stride,
+                                     int splits, float* __restrict__ c, int ldc, int NI, int NJ) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)NI * NJ) return;
+    const int i = (int)(idx / NJ), j = (int)(idx % NJ);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * split_stride + idx];
+    c[(size_t)i * ldc + j] = s;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+GemmProb gemm_prob(const float* a, int lda, const float* b, int ldb, int k, float* c, int ldc,
+                   int m, int n, const float* bias, int accumulate) {
+    GemmProb p{};
+    p.seg[0] = GemmSeg{a, b, lda, ldb, k};
+    p.nseg = 1;
+    p.m = m;
+    p.n = n;
+    p.c = c;
+    p.ldc = ldc;
+    p.bias = bias;
+    p.accumulate = accumulate;
+    return p;
+}
+
+void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb, int k) {
+    p.seg[1] = GemmSeg{a, b, lda, ldb, k};
+    p.nseg = 2;
+}
+
+static int check_prob(const GemmProb& p) {
+    for (int s = 0; s < p.nseg; ++s) {
+        const GemmSeg& g = p.seg[s];
+        if (!g.a || !g.b || g.k <= 0 || (g.lda & 3) || (g.ldb & 3) ||
+            (reinterpret_cast<uintptr_t>(g.a) & 15) || (reinterpret_cast<uintptr_t>(g.b) & 15) ||
+            g.lda < p4(g.k) || g.ldb < p4(g.k)) {
+            set_error("gemm: bad operand (seg %d: a=%p lda=%d b=%p ldb=%d k=%d)", s, (const void*)g.a,
+                      g.lda, (const void*)g.b, g.ldb, g.k);
+            return MARL_EINVAL;
+        }
+    }
+    if (p.m <= 0 || p.n <= 0) {
+        set_error("gemm: empty problem m=%d n=%d", p.m, p.n);
+        return MARL_EINVAL;
+    }
+    return MARL_OK;
+}
+
+int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
+    if (batch.count < 1 || batch.count > kMaxGemmBatch) return MARL_EINVAL;
+    int max_m = 0, max_n = 0;
+    int64_t blocks128 = 0;
+    for (int i = 0; i < batch.count; ++i) {
+        MARL_TRY(check_prob(batch.p[i]));
+        if (!batch.p[i].c) return MARL_EINVAL;
+        max_m = batch.p[i].m > max_m ? batch.p[i].m : max_m;
+        max_n = batch.p[i].n > max_n ? batch.p[i].n : max_n;
+        blocks128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 128);
+    }
+    if (blocks128 >= 256 && max_n >= 96) {
+        dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, batch);
+    } else {
+        dim3 grid((unsigned)cdiv(max_m, 64), (unsigned)cdiv(max_n, 64), (unsigned)batch.count);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, batch);
+    }
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
+    if (batch.count < 1 || batch.count > kMaxGemmBatch) return MARL_EINVAL;
+    int max_m = 0, max_n = 0;
+    for (int i = 0; i < batch.count; ++i) {
+        const GemmProb& p = batch.p[i];
+        MARL_TRY(check_prob(p));
+        if (!p.bias || !p.c_prev || !p.h_next || !p.c_next) return MARL_EINVAL;
+        max_m = p.m > max_m ? p.m : max_m;
+        max_n = p.n > max_n ? p.n : max_n;
+    }
+    dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 1, true>), grid, dim3(256), 0, st, batch);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+struct TnPlan {
+    int bm;  // 128 or 64 (square tiles)
+    int splits;
+    int64_t rows_per_split;
+};
+
+static TnPlan tn_plan(int ni, int nj, int64_t rows) {
+    TnPlan p;
+    p.bm = (ni >= 96 && nj >= 96) ? 128 : 64;
+    const int64_t tiles = cdiv(ni, p.bm) * cdiv(nj, p.bm);
+    int64_t s = cdiv(768, tiles);
+    const int64_t max_s = cdiv(rows, 4 * BK);  // at least 4 K tiles per split
+    if (s > max_s) s = max_s;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    int64_t rps = cdiv(cdiv(rows, s), BK) * BK;
+    p.splits = (int)cdiv(rows, rps);
+    p.rows_per_split = rps;
+    return p;
+}
+
+size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows) {
+    TnPlan p = tn_plan(ni, nj, rows);
+    return p.splits > 1 ? (size_t)p.splits * ni * nj * sizeof(float) : 0;
+}
+
+int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
+                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st) {
+    if (!a || !b || !c || ni <= 0 || nj <= 0 || rows <= 0 || (lda & 3) || (ldb & 3) ||
+        lda < p4(ni) || ldb < p4(nj) || (reinterpret_cast<uintptr_t>(a) & 15) ||
+        (reinterpret_cast<uintptr_t>(b) & 15)) {
+        set_error("gemm_tn: bad operand ni=%d nj=%d rows=%lld lda=%d ldb=%d", ni, nj,
+                  (long long)rows, lda, ldb);
+        return MARL_EINVAL;
+    }
+    TnPlan p = tn_plan(ni, nj, rows);
+    float* out = c;
+    int ldo = ldc;
+    int64_t stride = 0;
+    if (p.splits > 1) {
+        if (!scratch || scratch_bytes < (size_t)p.splits * ni * nj * sizeof(float)) {
+            set_error("gemm_tn: scratch too small");
+            return MARL_ESIZE;
+        }
+        out = scratch;
+        ldo = nj;
+        stride = (int64_t)ni * nj;
+    }
+    dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
+    if (p.bm == 128)
+        hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split);
+    MARL_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const int64_t n = (int64_t)ni * nj;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st,
+                           scratch, stride, p.splits, c, ldc, ni, nj);
+        MARL_LAUNCH_CHECK();
+    }
+    return MARL_OK;
+}
+
+}  // namespace marl

@@ -1,0 +1,765 @@
+// Row-wise and elementwise kernels of the episode: LayerNorm/GroupNorm + SiLU (forward and
+// backward), message mean, position embedding, LSTM-cell backward, policy sampling +
+// bounded move, deterministic reductions, weight (un)packing and Adam.
+// One 64-lane wave owns a row wherever a row reduction is needed.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace marl {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
+// d silu(y) / dy
+__device__ __forceinline__ float silu_grad(float y) {
+    const float s = 1.0f / (1.0f + expf(-y));
+    return s * (1.0f + y * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm (eps 1e-5, biased variance, affine) + SiLU     (Linear-LN-SiLU blocks of
+// networks/message.py, policy.py, prediction.py, state.py)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_silu_fwd_kernel(const float* __restrict__ z, int ldz,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ out, int ldo,
+                                                          float* __restrict__ stats, int64_t m,
+                                                          int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float* zr = z + row * ldz;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += zr[c];
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+    for (int c = lane; c < n; c += 64) {
+        const float d = zr[c] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + 1e-5f);
+    float* orow = out + row * ldo;
+    for (int c = lane; c < n; c += 64) {
+        const float y = (zr[c] - mean) * rstd * gamma[c] + beta[c];
+        orow[c] = silu_f(y);
+    }
+    if (stats && lane == 0) {
+        stats[row * 2] = mean;
+        stats[row * 2 + 1] = rstd;
+    }
+}
+
+int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
+                       int ldo, float* stats, int64_t m, int n, hipStream_t st) {
+    if (m <= 0) return MARL_OK;
+    hipLaunchKernelGGL(ln_silu_fwd_kernel, dim3((unsigned)cdiv(m, 4)), dim3(256), 0, st, z, ldz,
+                       gamma, beta, out, ldo, stats, m, n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+static int ln_rows_per_wave(int64_t m) {
+    int64_t r = cdiv(m, 4 * 1024);
+    if (r < 1) r = 1;
+    if (r > 16) r = 16;
+    return (int)r;
+}
+int ln_bwd_blocks(int64_t m) { return (int)cdiv(m, 4 * ln_rows_per_wave(m)); }
+
+// part[blk][0][n] = sum_rows dy * xhat (dgamma), part[blk][1][n] = sum_rows dy (dbeta)
+__global__ __launch_bounds__(256) void ln_silu_bwd_kernel(
+    const float* __restrict__ da, int ldda, const float* __restrict__ z, int ldz,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dz, int lddz, float* __restrict__ part,
+    int64_t m, int n, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [4][2][n]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* ga = sacc + (size_t)wave * 2 * n;
+    float* gb = ga + n;
+    for (int c = lane; c < n; c += 64) {
+        ga[c] = 0.f;
+        gb[c] = 0.f;
+    }
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + rr;
+        if (row >= m) break;
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        const float* zr = z + row * ldz;
+        const float* dar = da + row * ldda;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < n; c += 64) {
+            const float xh = (zr[c] - mean) * rstd;
+            const float g = gamma[c];
+            const float dy = dar[c] * silu_grad(g * xh + beta[c]);
+            const float dxh = dy * g;
+            s1 += dxh;
+            s2 += dxh * xh;
+            ga[c] += dy * xh;
+            gb[c] += dy;
+        }
+        const float m1 = wave_sum(s1) / (float)n;
+        const float m2 = wave_sum(s2) / (float)n;
+        float* dzr = dz + row * lddz;
+        for (int c = lane; c < n; c += 64) {
+            const float xh = (zr[c] - mean) * rstd;
+            const float g = gamma[c];
+            const float dxh = dar[c] * silu_grad(g * xh + beta[c]) * g;
+            dzr[c] = rstd * (dxh - m1 - xh * m2);
+        }
+    }
+    __syncthreads();
+    float* p = part + (size_t)blockIdx.x * 2 * n;
+    for (int c = threadIdx.x; c < 2 * n; c += 256)
+        p[c] = ((sacc[c] + sacc[2 * n + c]) + sacc[4 * n + c]) + sacc[6 * n + c];
+}
+
+int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
+                       const float* gamma, const float* beta, float* dz, int lddz, float* part,
+                       int64_t m, int n, hipStream_t st) {
+    if (m <= 0) return MARL_OK;
+    if (n > 2048) {
+        set_error("LayerNorm width %d > 2048 unsupported", n);
+        return MARL_ELIMIT;
+    }
+    const int rpw = ln_rows_per_wave(m);
+    hipLaunchKernelGGL(ln_silu_bwd_kernel, dim3((unsigned)ln_bwd_blocks(m)), dim3(256),
+                       (size_t)8 * n * sizeof(float), st, da, ldda, z, ldz, stats, gamma, beta, dz,
+                       lddz, part, m, n, rpw);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// out[c] (+)= sum_p part[p * stride + c]; 64 columns x 4 interleaved part groups per block,
+// groups combined in a fixed order -> bit-reproducible.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
+                                                              int64_t nparts, int64_t stride,
+                                                              float* __restrict__ out, int n,
+                                                              int accumulate) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < n)
+        for (int64_t p = grp; p < nparts; p += 4) s += part[p * stride + c];
+    sh[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < n) {
+        float t = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+        if (accumulate) t += out[c];
+        out[c] = t;
+    }
+}
+
+int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, float* out, int n,
+                           int accumulate, hipStream_t st) {
+    if (n <= 0) return MARL_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, part,
+                       nparts, stride, out, n, accumulate);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ __launch_bounds__(256) void reduce_affine_kernel(const float* __restrict__ part,
+                                                            int64_t nparts, int n,
+                                                            float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta,
+                                                            int accumulate) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;  // column in [0, 2n): gamma then beta
+    float s = 0.f;
+    if (c < 2 * n)
+        for (int64_t p = grp; p < nparts; p += 4) s += part[p * 2 * n + c];
+    sh[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < 2 * n) {
+        float t = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+        float* o = c < n ? dgamma + c : dbeta + (c - n);
+        if (accumulate) t += *o;
+        *o = t;
+    }
+}
+
+int launch_reduce_affine(const float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
+                         int accumulate, hipStream_t st) {
+    if (n <= 0) return MARL_OK;
+    hipLaunchKernelGGL(reduce_affine_kernel, dim3((unsigned)cdiv(2 * n, 64)), dim3(256), 0, st,
+                       part, nparts, n, dgamma, dbeta, accumulate);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// column sums (bias gradients): stage 1 -> scratch[blk][n], stage 2 -> out
+int colsum_blocks(int64_t rows) {
+    int64_t b = cdiv(rows, 256);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld,
+                                                     int64_t rows, int n, int cw,
+                                                     int64_t rows_per_blk,
+                                                     float* __restrict__ scratch) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rs = 64 / cw;  // row sub-lanes per wave
+    const int col = blockIdx.y * 64 + (lane % cw);
+    const int rsub = lane / cw;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    int64_t r1 = r0 + rows_per_blk;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    if (col < n)
+        for (int64_t r = r0 + wave * rs + rsub; r < r1; r += 4 * rs) s += x[r * ld + col];
+    for (int o = cw; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && rsub == 0 && col < n)
+        scratch[(size_t)blockIdx.x * n + col] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+
+int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float* scratch,
+                  hipStream_t st) {
+    if (rows <= 0 || n <= 0) return MARL_OK;
+    const int nb = colsum_blocks(rows);
+    int cw = 1;
+    while (cw < n && cw < 64) cw <<= 1;
+    const int64_t rpb = cdiv(rows, nb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb, (unsigned)cdiv(n, 64)), dim3(256), 0, st,
+                       x, ld, rows, n, cw, rpb, scratch);
+    MARL_LAUNCH_CHECK();
+    return launch_reduce_partials(scratch, nb, n, out, n, 0, st);
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm (eps 1e-5, biased variance over (C/G) * P) + SiLU on NHWC rows
+// (networks/vision.py:33-38)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const float* __restrict__ z,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ out, int64_t ldo,
+                                                          int out_chw, float* __restrict__ stats,
+                                                          int64_t rows, int P, int C, int G) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int Cg = C / G;
+    const int cnt = P * Cg;
+    const float* zr = z + row * (int64_t)P * C;
+    float* orow = out + row * ldo;
+    for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+        for (int i = lane; i < cnt; i += 64) s += zr[(i / Cg) * C + g * Cg + (i % Cg)];
+        const float mean = wave_sum(s) / (float)cnt;
+        float q = 0.f;
+        for (int i = lane; i < cnt; i += 64) {
+            const float d = zr[(i / Cg) * C + g * Cg + (i % Cg)] - mean;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+        for (int i = lane; i < cnt; i += 64) {
+            const int pos = i / Cg, c = g * Cg + (i % Cg);
+            const float y = (zr[pos * C + c] - mean) * rstd * gamma[c] + beta[c];
+            orow[out_chw ? (int64_t)c * P + pos : (int64_t)pos * C + c] = silu_f(y);
+        }
+        if (stats && lane == 0) {
+            stats[(row * G + g) * 2] = mean;
+            stats[(row * G + g) * 2 + 1] = rstd;
+        }
+    }
+}
+
+int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
+                       int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
+                       hipStream_t st) {
+    if (rows <= 0) return MARL_OK;
+    hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, z,
+                       gamma, beta, out, ldo, out_chw, stats, rows, P, C, G);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+static int gn_rows_per_wave(int64_t rows) {
+    int64_t r = cdiv(rows, 4 * 2048);
+    if (r < 1) r = 1;
+    if (r > 64) r = 64;
+    return (int)r;
+}
+int gn_bwd_blocks(int64_t rows) { return (int)cdiv(rows, 4 * gn_rows_per_wave(rows)); }
+
+// Lane (cc, pslot) owns channel g*Cg+cc and walks positions pslot, pslot+64/Cg, ... so the
+// per-channel dgamma/dbeta sums have a single owner (no LDS races, fixed order).
+__global__ __launch_bounds__(256) void gn_silu_bwd_kernel(
+    const float* __restrict__ da, int64_t ldda, int da_chw, const float* __restrict__ z,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dz, float* __restrict__ part,
+    int64_t rows, int P, int C, int G, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [4][2][C]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* ga = sacc + (size_t)wave * 2 * C;
+    float* gb = ga + C;
+    for (int c = lane; c < C; c += 64) {
+        ga[c] = 0.f;
+        gb[c] = 0.f;
+    }
+    const int Cg = C / G;
+    const int cc = lane % Cg, pslot = lane / Cg, pstep = 64 / Cg;
+    const float inv_cnt = 1.0f / (float)(P * Cg);
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + rr;
+        if (row >= rows) break;
+        const float* zr = z + row * (int64_t)P * C;
+        const float* dar = da + row * ldda;
+        float* dzr = dz + row * (int64_t)P * C;
+        for (int g = 0; g < G; ++g) {
+            const float mean = stats[(row * G + g) * 2], rstd = stats[(row * G + g) * 2 + 1];
+            const int c = g * Cg + cc;
+            const float gm = gamma[c], bt = beta[c];
+            float s1 = 0.f, s2 = 0.f, pg = 0.f, pb = 0.f;
+            for (int pos = pslot; pos < P; pos += pstep) {
+                const float xh = (zr[pos * C + c] - mean) * rstd;
+                const float dav = dar[da_chw ? (int64_t)c * P + pos : (int64_t)pos * C + c];
+                const float dy = dav * silu_grad(gm * xh + bt);
+                const float dxh = dy * gm;
+                s1 += dxh;
+                s2 += dxh * xh;
+                pg += dy * xh;
+                pb += dy;
+            }
+            const float m1 = wave_sum(s1) * inv_cnt;
+            const float m2 = wave_sum(s2) * inv_cnt;
+            for (int o = Cg; o < 64; o <<= 1) {
+                pg += __shfl_xor(pg, o);
+                pb += __shfl_xor(pb, o);
+            }
+            if (pslot == 0) {
+                ga[c] += pg;
+                gb[c] += pb;
+            }
+            for (int pos = pslot; pos < P; pos += pstep) {
+                const float xh = (zr[pos * C + c] - mean) * rstd;
+                const float dav = dar[da_chw ? (int64_t)c * P + pos : (int64_t)pos * C + c];
+                const float dxh = dav * silu_grad(gm * xh + bt) * gm;
+                dzr[pos * C + c] = rstd * (dxh - m1 - xh * m2);
+            }
+        }
+    }
+    __syncthreads();
+    float* p = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256)
+        p[c] = ((sacc[c] + sacc[2 * C + c]) + sacc[4 * C + c]) + sacc[6 * C + c];
+}
+
+int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
+                       const float* stats, const float* gamma, const float* beta, float* dz,
+                       float* part, int64_t rows, int P, int C, int G, hipStream_t st) {
+    if (rows <= 0) return MARL_OK;
+    const int Cg = C / G;
+    if (Cg > 64 || (Cg & (Cg - 1)) != 0 || C > 2048) {
+        set_error("GroupNorm backward needs channels/group a power of two <= 64 (got %d)", Cg);
+        return MARL_ELIMIT;
+    }
+    const int rpw = gn_rows_per_wave(rows);
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3((unsigned)gn_bwd_blocks(rows)), dim3(256),
+                       (size_t)8 * C * sizeof(float), st, da, ldda, da_chw, z, stats, gamma, beta,
+                       dz, part, rows, P, C, G, rpw);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// aggregate_messages (networks/message.py:5-17): (sum_a m - m) / (Na - 1)
+// ---------------------------------------------------------------------------
+__global__ void agg_msg_kernel(const float* __restrict__ m, float* __restrict__ out, int ld,
+                               int na, int nb, int n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nb * n) return;
+    const int b = (int)(idx / n), k = (int)(idx % n);
+    if (na == 1) {
+        out[(size_t)b * ld + k] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int a = 0; a < na; ++a) s += m[((size_t)a * nb + b) * ld + k];
+    const float den = (float)(na - 1);
+    for (int a = 0; a < na; ++a) {
+        const size_t o = ((size_t)a * nb + b) * ld + k;
+        out[o] = (s - m[o]) / den;
+    }
+}
+
+int launch_agg_msg(const float* m, float* out, int ld, int na, int nb, int n, hipStream_t st) {
+    const int64_t tot = (int64_t)nb * n;
+    hipLaunchKernelGGL(agg_msg_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, m, out, ld,
+                       na, nb, n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// map_pos (networks/state.py:14-16) on normalised positions (core/environment.py:74-81)
+// ---------------------------------------------------------------------------
+__global__ void pos_embed_fwd_kernel(const int32_t* __restrict__ pos,
+                                     const float* __restrict__ npos_in, int H, int W_,
+                                     const float* __restrict__ W, const float* __restrict__ b,
+                                     const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ npos4,
+                                     float* __restrict__ z, int ldz, float* __restrict__ stats,
+                                     float* __restrict__ out, int ldo, int64_t rows, int nd) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float p0 = npos_in ? npos_in[r * 2] : (float)pos[r * 2] / (float)H;
+    const float p1 = npos_in ? npos_in[r * 2 + 1] : (float)pos[r * 2 + 1] / (float)W_;
+    if (npos4) {
+        npos4[r * 4] = p0;
+        npos4[r * 4 + 1] = p1;
+    }
+    float* zr = z + r * ldz;
+    float s = 0.f;
+    for (int j = 0; j < nd; ++j) {
+        const float v = b[j] + p0 * W[4 * j] + p1 * W[4 * j + 1];  // W packed [nd, 4]
+        zr[j] = v;
+        s += v;
+    }
+    const float mean = s / (float)nd;
+    float q = 0.f;
+    for (int j = 0; j < nd; ++j) {
+        const float d = zr[j] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(q / (float)nd + 1e-5f);
+    if (stats) {
+        stats[r * 2] = mean;
+        stats[r * 2 + 1] = rstd;
+    }
+    float* orow = out + r * ldo;
+    for (int j = 0; j < nd; ++j) orow[j] = silu_f((zr[j] - mean) * rstd * gamma[j] + beta[j]);
+}
+
+int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w, const float* W,
+                         const float* b, const float* gamma, const float* beta, float* npos4,
+                         float* z, int ldz, float* stats, float* out, int ldo, int64_t rows, int nd,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(pos_embed_fwd_kernel, dim3((unsigned)cdiv(rows, 128)), dim3(128), 0, st, pos,
+                       npos_in, h, w, W, b, gamma, beta, npos4, z, ldz, stats, out, ldo, rows, nd);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LSTM cell backward (pointwise part). gates holds activated i|f|g|o on entry and the
+// pre-activation gradients on exit; dc holds dL/dc_t on entry and dL/dc_{t-1} on exit.
+// ---------------------------------------------------------------------------
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, int lddh,
+                                     float* __restrict__ dc, int lddc, float* __restrict__ gates,
+                                     int ldg, const float* __restrict__ c_prev,
+                                     const float* __restrict__ c_new, int ldc, int64_t rows,
+                                     int n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * n) return;
+    const int64_t r = idx / n;
+    const int u = (int)(idx % n);
+    float* g = gates + r * ldg + u;
+    const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
+    const float tc = tanhf(c_new[r * ldc + u]);
+    const float dhv = dh[r * lddh + u];
+    const float dcv = dhv * go * (1.0f - tc * tc) + dc[r * lddc + u];
+    g[0] = dcv * gg * gi * (1.0f - gi);
+    g[n] = dcv * c_prev[r * ldc + u] * gf * (1.0f - gf);
+    g[2 * n] = dcv * gi * (1.0f - gg * gg);
+    g[3 * n] = dhv * tc * go * (1.0f - go);
+    dc[r * lddc + u] = dcv * gf;
+}
+
+int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
+                         const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
+                         hipStream_t st) {
+    const int64_t tot = rows * n;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, dh,
+                       lddh, dc, lddc, gates, ldg, c_prev, c_new, ldc, rows, n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Policy output layer + softmax + multinomial (argmax p/q) + log-prob + bounded move
+// (networks/policy.py:15-16, core/agent.py:53-61, core/environment.py:56-66,128-150)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.R) return;
+    const float* ar = A.a_pol + (size_t)r * A.ld_a;
+    float p[MARL_MAX_ACTIONS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) {
+        p[j] = 0.f;
+        if (j < A.nA) {
+            const float* wj = A.w1 + (size_t)j * A.ldw;
+            float s = 0.f;
+            for (int k = lane; k < A.nla; k += 64) s += ar[k] * wj[k];
+            p[j] = wave_sum(s) + A.b1[j];
+            mx = fmaxf(mx, p[j]);
+        }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+        if (j < A.nA) {
+            p[j] = expf(p[j] - mx);
+            den += p[j];
+        }
+    int act = 0;
+    float best = -INFINITY, pa = 0.f;
+#pragma unroll
+    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+        if (j < A.nA) {
+            p[j] = p[j] / den;
+            if (A.noise) {
+                const float sc = p[j] / A.noise[(size_t)r * A.nA + j];
+                if (sc > best) {
+                    best = sc;
+                    act = j;
+                }
+            }
+        }
+    if (!A.step_logp) {  // standalone step API: probabilities only
+        if (lane == 0)
+#pragma unroll
+            for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+                if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
+        return;
+    }
+    if (A.forced) act = (int)A.forced[r];
+#pragma unroll
+    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+        if (j == act) pa = p[j];
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+            if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
+        A.actions_i32[r] = act;
+        A.step_logp[r] = logf(pa);
+        const int p0 = A.pos_in[r * 2], p1 = A.pos_in[r * 2 + 1];
+        const int q0 = p0 + A.table[act][0], q1 = p1 + A.table[act][1];
+        const bool ok = q0 >= 0 && q0 + A.f < A.H && q1 >= 0 && q1 + A.f < A.W;
+        const int n0 = ok ? q0 : p0, n1 = ok ? q1 : p1;
+        A.pos_out[r * 2] = n0;
+        A.pos_out[r * 2 + 1] = n1;
+        if (A.step_pos) {
+            A.step_pos[(size_t)r * 2] = n0;
+            A.step_pos[(size_t)r * 2 + 1] = n1;
+        }
+        if (A.step_actions) A.step_actions[r] = act;
+    }
+}
+
+int launch_sample(const SampleArgs& a, hipStream_t st) {
+    if (a.nA > MARL_MAX_ACTIONS) return MARL_ELIMIT;
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// permuted copies (weight packing / gradient unpacking)
+// ---------------------------------------------------------------------------
+__global__ void permute_kernel(const PermBatch B) {
+    const PermDesc& d = B.d[blockIdx.y];
+    const int64_t tot = (int64_t)d.rows * d.cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / d.cols), c = (int)(idx % d.cols);
+        const int64_t so = (int64_t)(r / d.rd) * d.rs1 + (int64_t)(r % d.rd) * d.rs2 +
+                           (int64_t)(c / d.cd) * d.cs1 + (int64_t)(c % d.cd) * d.cs2;
+        float v = d.src[so];
+        if (d.src2) v += d.src2[so];
+        d.dst[(int64_t)r * d.dst_ld + c] = v;
+    }
+}
+
+int launch_permute(const PermBatch& b, hipStream_t st) {
+    if (b.count <= 0) return MARL_OK;
+    if (b.count > kMaxPerm) return MARL_EINVAL;
+    int64_t mx = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const int64_t t = (int64_t)b.d[i].rows * b.d[i].cols;
+        mx = t > mx ? t : mx;
+    }
+    int64_t gx = cdiv(mx, 256);
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(permute_kernel, dim3((unsigned)gx, (unsigned)b.count), dim3(256), 0, st, b);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Adam (th.optim.Adam single-tensor update order, training/trainer.py:33,116)
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            float step_size, float inv_sqrt_bc2, float beta1, float beta2,
+                            float eps, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * grad_scale;
+        const float mi = m[i] + (1.0f - beta1) * (gr - m[i]);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * (gr * gr);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_over_bc1,
+                float inv_sqrt_bc2, float beta1, float beta2, float eps, float grad_scale,
+                hipStream_t st) {
+    if (n <= 0) return MARL_OK;
+    int64_t gx = cdiv(n, 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, st, p, g, m, v, n,
+                       lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, grad_scale);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small elementwise helpers
+// ---------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
+    if (n <= 0) return MARL_OK;
+    int64_t gx = cdiv(n, 256);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)gx), dim3(256), 0, st, p, n, v);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float* __restrict__ dst,
+                              int64_t ldd, int64_t rows, int cols) {
+    const int64_t tot = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+int launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
+                  hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return MARL_OK;
+    int64_t gx = cdiv(rows * cols, 256);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)gx), dim3(256), 0, st, src, lds, dst, ldd, rows,
+                       cols);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ void i64_to_i32_kernel(const int64_t* __restrict__ s, int32_t* __restrict__ d,
+                                  int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (int32_t)s[i];
+}
+int launch_i64_to_i32(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return MARL_OK;
+    hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, src, dst,
+                       n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ void policy_dlogits_kernel(const float* __restrict__ dlogp,
+                                      const float* __restrict__ probs,
+                                      const int32_t* __restrict__ actions, float* __restrict__ out,
+                                      int ld, int64_t rows, int nA) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nA) return;
+    const int64_t r = idx / nA;
+    const int j = (int)(idx % nA);
+    const float g = dlogp ? dlogp[r] : 0.f;
+    out[r * ld + j] = g * ((j == actions[r] ? 1.0f : 0.0f) - probs[r * nA + j]);
+}
+int launch_policy_dlogits(const float* dlogp, const float* probs, const int32_t* actions,
+                          float* out, int ld, int64_t rows, int nA, hipStream_t st) {
+    hipLaunchKernelGGL(policy_dlogits_kernel, dim3((unsigned)cdiv(rows * nA, 256)), dim3(256), 0,
+                       st, dlogp, probs, actions, out, ld, rows, nA);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, int lda,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ b,
+                                                     float* __restrict__ out, int64_t rows,
+                                                     int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* ar = a + r * lda;
+    float s = 0.f;
+    for (int k = lane; k < n; k += 64) s += ar[k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s + b[0];
+}
+int launch_rowdot(const float* a, int lda, const float* w, const float* b, float* out,
+                  int64_t rows, int n, hipStream_t st) {
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, a, lda, w, b,
+                       out, rows, n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+__global__ void softmax_rows_kernel(const float* __restrict__ logits, int ld,
+                                    float* __restrict__ probs, int64_t rows, int n) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* l = logits + r * ld;
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) mx = fmaxf(mx, l[j]);
+    float den = 0.f;
+    for (int j = 0; j < n; ++j) den += expf(l[j] - mx);
+    for (int j = 0; j < n; ++j) probs[r * n + j] = expf(l[j] - mx) / den;
+}
+int launch_softmax_rows(const float* logits, int ld, float* probs, int64_t rows, int n,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 128)), dim3(128), 0, st,
+                       logits, ld, probs, rows, n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+}  // namespace marl
+
+extern "C" const char* marl_last_error(void) { return marl::last_error(); }

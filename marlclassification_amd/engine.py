@@ -1,0 +1,348 @@
+"""Thin host-side driver over libmarl_hip.so: builds ``marl_config`` structs, owns the two
+workspaces the C ABI asks the caller to provide, and turns torch tensors into raw device
+pointers + the current HIP stream.  PyTorch is used for device memory, streams and (in
+``parallel.py``) ``torch.distributed`` only - every computation happens in the HIP library.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch as th
+
+from . import _lib
+from ._lib import MARL_NPARAMS, MarlConfig, P, check
+
+# Conv stacks of the reference's feature extractors (networks/vision.py:55-86,123-127):
+# channels entering / leaving every Conv-GroupNorm-SiLU block and the GroupNorm groups.
+CNN_SPECS: Dict[str, Tuple[List[int], List[int]]] = {
+    "mnist": ([1, 8, 16], [2, 4]),
+    "resisc45": ([3, 16, 32, 64], [2, 4, 8]),
+    "aid": ([3, 16, 32, 64, 128], [2, 4, 8, 16]),
+    "worldstrat": ([3, 16, 32, 64, 128, 256], [2, 4, 8, 16, 32]),
+    "skin_cancer": ([3, 16, 32, 64], [2, 4, 8]),
+}
+
+_MW = "_ModelsWrapper__"
+_CNN_PREFIX = _MW + "map_obs._Generic2dCnnModule__layers."
+_LSTM = "._LSTMCellWrapper__lstm."
+
+
+def _mlp_names(prefix: str, tag: str, two_ln: bool) -> Dict[str, int]:
+    out = {
+        f"{_MW}{prefix}.0.weight": P[f"{tag}_W0"],
+        f"{_MW}{prefix}.0.bias": P[f"{tag}_B0"],
+        f"{_MW}{prefix}.1.weight": P[f"{tag}_LN0W" if two_ln else f"{tag}_LNW"],
+        f"{_MW}{prefix}.1.bias": P[f"{tag}_LN0B" if two_ln else f"{tag}_LNB"],
+        f"{_MW}{prefix}.3.weight": P[f"{tag}_W1"],
+        f"{_MW}{prefix}.3.bias": P[f"{tag}_B1"],
+    }
+    if two_ln:
+        out[f"{_MW}{prefix}.4.weight"] = P[f"{tag}_LN1W"]
+        out[f"{_MW}{prefix}.4.bias"] = P[f"{tag}_LN1B"]
+    return out
+
+
+def state_dict_slots(n_cnn_layers: int) -> Dict[str, int]:
+    """Reference state-dict key (name-mangled) -> slot of the C parameter
+    table (enum in include/marl_hip.h)."""
+    m: Dict[str, int] = {}
+    for l in range(n_cnn_layers):
+        m[f"{_CNN_PREFIX}{3 * l}.weight"] = 4 * l
+        m[f"{_CNN_PREFIX}{3 * l}.bias"] = 4 * l + 1
+        m[f"{_CNN_PREFIX}{3 * l + 1}.weight"] = 4 * l + 2
+        m[f"{_CNN_PREFIX}{3 * l + 1}.bias"] = 4 * l + 3
+    m[f"{_MW}map_pos.0.weight"] = P["POS_W"]
+    m[f"{_MW}map_pos.0.bias"] = P["POS_B"]
+    m[f"{_MW}map_pos.1.weight"] = P["POS_LNW"]
+    m[f"{_MW}map_pos.1.bias"] = P["POS_LNB"]
+    m.update(_mlp_names("encode_msg", "ENC", True))
+    m.update(_mlp_names("decode_msg", "DEC", True))
+    for unit, tag in (("belief_unit", "LB"), ("action_unit", "LA")):
+        m[f"{_MW}{unit}{_LSTM}weight_ih"] = P[f"{tag}_WIH"]
+        m[f"{_MW}{unit}{_LSTM}weight_hh"] = P[f"{tag}_WHH"]
+        m[f"{_MW}{unit}{_LSTM}bias_ih"] = P[f"{tag}_BIH"]
+        m[f"{_MW}{unit}{_LSTM}bias_hh"] = P[f"{tag}_BHH"]
+    m.update(_mlp_names("policy", "POL", False))
+    m.update(_mlp_names("critic", "CRI", False))
+    m.update(_mlp_names("predict", "PRE", False))
+    return m
+
+
+@dataclass
+class ModelSpec:
+    """Everything ``marl_config`` needs that does not depend on the batch."""
+
+    ft_extr: str
+    window: int
+    n_b: int
+    n_a: int
+    n_m: int
+    n_m_o: int
+    n_d: int
+    nb_class: int
+    nlb: int
+    nla: int
+    actions: List[List[int]] = field(
+        default_factory=lambda: [[1, 0], [-1, 0], [0, 1], [0, -1]]
+    )
+
+    def config(self, nb_agents: int, batch: int, nb_steps: int, img_c: int, h: int, w: int) -> MarlConfig:
+        if self.ft_extr not in CNN_SPECS:
+            raise ValueError(
+                f'feature extractor "{self.ft_extr}" has no HIP implementation '
+                f"(supported: {sorted(CNN_SPECS)})"
+            )
+        ch, groups = CNN_SPECS[self.ft_extr]
+        if len(self.actions) > _lib.MARL_MAX_ACTIONS:
+            raise ValueError("too many actions")
+        cfg = MarlConfig()
+        cfg.nb_agents, cfg.batch, cfg.nb_steps = nb_agents, batch, nb_steps
+        cfg.img_c, cfg.img_h, cfg.img_w = img_c, h, w
+        cfg.window = self.window
+        cfg.cnn_layers = len(groups)
+        for i, c in enumerate(ch):
+            cfg.cnn_ch[i] = c
+        for i, g in enumerate(groups):
+            cfg.cnn_groups[i] = g
+        cfg.n_b, cfg.n_a, cfg.n_m, cfg.n_m_o, cfg.n_d = self.n_b, self.n_a, self.n_m, self.n_m_o, self.n_d
+        cfg.nb_action, cfg.nb_class = len(self.actions), self.nb_class
+        cfg.nlb, cfg.nla = self.nlb, self.nla
+        for j, (d0, d1) in enumerate(self.actions):
+            cfg.actions[j][0], cfg.actions[j][1] = d0, d1
+        return cfg
+
+    @property
+    def n_cnn_layers(self) -> int:
+        return len(CNN_SPECS[self.ft_extr][1])
+
+
+def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: th.device) -> int:
+    return th.cuda.current_stream(device).cuda_stream
+
+
+def _need(t: th.Tensor, dtype: th.dtype, name: str) -> th.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} lives on {t.device}: the HIP path only runs on a GPU "
+            "(there is no CPU implementation in this package)"
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+@dataclass
+class EpisodeTensors:
+    step_preds: th.Tensor
+    step_log_probas: th.Tensor
+    step_values: th.Tensor
+    step_pos: th.Tensor
+    step_actions: th.Tensor
+
+
+class HipEngine:
+    """Owns workspaces for one model on one device and issues the C ABI calls."""
+
+    def __init__(self, spec: ModelSpec, device: th.device) -> None:
+        self.lib = _lib.load()
+        self.spec = spec
+        self.device = th.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEngine needs a GPU device (torch 'cuda' == HIP on ROCm)")
+        self.slots = state_dict_slots(spec.n_cnn_layers)
+        self._wws: Optional[th.Tensor] = None
+        self._ews: Dict[Tuple, th.Tensor] = {}
+        self._cfg_key: Optional[Tuple] = None
+        self.cfg: Optional[MarlConfig] = None
+        self._packed_version: Optional[int] = None
+
+    # -- configuration / workspaces -------------------------------------------------
+    def configure(self, nb_agents: int, batch: int, nb_steps: int, img_shape: Sequence[int]) -> MarlConfig:
+        key = (nb_agents, batch, nb_steps, tuple(img_shape))
+        if key != self._cfg_key:
+            c, h, w = img_shape
+            self.cfg = self.spec.config(nb_agents, batch, nb_steps, c, h, w)
+            self._cfg_key = key
+        assert self.cfg is not None
+        return self.cfg
+
+    def _sizes(self, train: bool) -> Tuple[int, int]:
+        wb, eb = C.c_size_t(0), C.c_size_t(0)
+        check(self.lib.marl_workspace_sizes(C.byref(self.cfg), int(train), C.byref(wb), C.byref(eb)))
+        return wb.value, eb.value
+
+    def weights_ws(self) -> th.Tensor:
+        if self._wws is None:
+            wb, _ = self._sizes(True)
+            self._wws = th.zeros(wb // 4 + 64, dtype=th.float32, device=self.device)
+        return self._wws
+
+    def episode_ws(self, train: bool) -> th.Tensor:
+        key = (self._cfg_key, train)
+        ws = self._ews.get(key)
+        if ws is None:
+            _, eb = self._sizes(train)
+            # keep at most one workspace per mode: shapes rarely change
+            for k in [k for k in self._ews if k[1] == train]:
+                del self._ews[k]
+            ws = th.zeros(eb // 4 + 64, dtype=th.float32, device=self.device)
+            self._ews[key] = ws
+        return ws
+
+    def _table(self, tensors: Dict[str, th.Tensor]) -> "C.Array":
+        arr = (C.c_void_p * MARL_NPARAMS)()
+        for name, slot in self.slots.items():
+            t = tensors[name]
+            if not t.is_cuda or t.dtype != th.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous fp32 GPU tensor")
+            arr[slot] = t.data_ptr()
+        return arr
+
+    # -- calls ----------------------------------------------------------------------
+    def pack(self, params: Dict[str, th.Tensor]) -> None:
+        """marl_pack_weights: refresh the padded / transposed copies after an update."""
+        assert self.cfg is not None, "configure() first"
+        check(self.lib.marl_pack_weights(C.byref(self.cfg), self._table(params),
+                                         self.weights_ws().data_ptr(), _stream(self.device)))
+
+    def episode_forward(
+        self, img: th.Tensor, pos0: th.Tensor, h0: th.Tensor, c0: th.Tensor, hc0: th.Tensor,
+        cc0: th.Tensor, noise: Optional[th.Tensor], forced_actions: Optional[th.Tensor] = None,
+        train: bool = True,
+    ) -> EpisodeTensors:
+        cfg = self.cfg
+        assert cfg is not None
+        na, nb, ns = cfg.nb_agents, cfg.batch, cfg.nb_steps
+        dev = self.device
+        img = _need(img, th.float32, "img")
+        pos0 = _need(pos0, th.int64, "pos0")
+        h0, c0, hc0, cc0 = (_need(t, th.float32, n) for t, n in
+                            ((h0, "h0"), (c0, "c0"), (hc0, "hc0"), (cc0, "cc0")))
+        if noise is not None:
+            noise = _need(noise, th.float32, "noise")
+        if forced_actions is not None:
+            forced_actions = _need(forced_actions, th.int64, "forced_actions")
+        out = EpisodeTensors(
+            th.empty(ns, na, nb, cfg.nb_class, device=dev),
+            th.empty(ns, na, nb, device=dev),
+            th.empty(ns, na, nb, device=dev),
+            th.empty(ns, na, nb, 2, dtype=th.int64, device=dev),
+            th.empty(ns, na, nb, dtype=th.int64, device=dev),
+        )
+        check(self.lib.marl_episode_forward(
+            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(train).data_ptr(),
+            img.data_ptr(), pos0.data_ptr(), h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(),
+            cc0.data_ptr(), _ptr(noise), _ptr(forced_actions),
+            out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
+            out.step_pos.data_ptr(), out.step_actions.data_ptr(), int(train), _stream(dev)))
+        return out
+
+    def episode_backward(
+        self, g_preds: Optional[th.Tensor], g_logp: Optional[th.Tensor],
+        g_values: Optional[th.Tensor], grads: Dict[str, th.Tensor],
+    ) -> None:
+        cfg = self.cfg
+        assert cfg is not None
+        gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
+        gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
+        gv = None if g_values is None else _need(g_values, th.float32, "g_values")
+        check(self.lib.marl_episode_backward(
+            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(True).data_ptr(),
+            _ptr(gp), _ptr(gl), _ptr(gv), self._table(grads), _stream(self.device)))
+
+    def a2c_loss(
+        self, out: EpisodeTensors, y: th.Tensor, gamma: float, phase: int = 0,
+        bufs: Optional[Tuple[th.Tensor, ...]] = None,
+    ) -> Tuple[th.Tensor, th.Tensor, th.Tensor, th.Tensor, th.Tensor]:
+        """Returns (g_preds, g_logp, g_values, scalars[4], adv_stats[3] float64)."""
+        cfg = self.cfg
+        assert cfg is not None
+        dev = self.device
+        y = _need(y, th.int64, "y")
+        if bufs is None:
+            bufs = (
+                th.empty_like(out.step_preds), th.empty_like(out.step_log_probas),
+                th.empty_like(out.step_values), th.zeros(4, device=dev),
+                th.zeros(3, dtype=th.float64, device=dev),
+            )
+        gp, gl, gv, sc, st = bufs
+        check(self.lib.marl_a2c_loss_fwd_bwd(
+            C.byref(cfg), self.episode_ws(True).data_ptr(), out.step_preds.data_ptr(),
+            out.step_log_probas.data_ptr(), out.step_values.data_ptr(), y.data_ptr(),
+            C.c_float(gamma), gp.data_ptr(), gl.data_ptr(), gv.data_ptr(), sc.data_ptr(),
+            st.data_ptr(), phase, _stream(dev)))
+        return bufs
+
+    def adam(
+        self, params: th.Tensor, grads: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor,
+        step: int, lr: float, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+        grad_scale: float = 1.0,
+    ) -> None:
+        for t in (params, grads, exp_avg, exp_avg_sq):
+            if not t.is_cuda or t.dtype != th.float32 or not t.is_contiguous():
+                raise RuntimeError("adam buffers must be contiguous fp32 GPU tensors")
+        check(self.lib.marl_adam_step(
+            params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+            params.numel(), step, lr, betas[0], betas[1], eps, grad_scale, _stream(self.device)))
+
+    def step_forward(
+        self, obs: th.Tensor, msg: th.Tensor, norm_pos: th.Tensor, h: th.Tensor, c: th.Tensor,
+        hc: th.Tensor, cc: th.Tensor,
+    ) -> Tuple[th.Tensor, ...]:
+        """marl_step_forward: (probs, values, preds, new_msg, h, c, hc, cc) in [Na,Nb,..]."""
+        cfg = self.cfg
+        assert cfg is not None
+        na, nb = cfg.nb_agents, cfg.batch
+        dev = self.device
+        ins = [_need(t, th.float32, n) for t, n in (
+            (obs, "obs"), (msg, "msg"), (norm_pos, "norm_pos"), (h, "h"), (c, "c"), (hc, "hc"),
+            (cc, "cc"))]
+        outs = (
+            th.empty(na, nb, cfg.nb_action, device=dev), th.empty(na, nb, device=dev),
+            th.empty(na, nb, cfg.nb_class, device=dev), th.empty(na, nb, cfg.n_m, device=dev),
+            th.empty(na, nb, cfg.n_b, device=dev), th.empty(na, nb, cfg.n_b, device=dev),
+            th.empty(na, nb, cfg.n_a, device=dev), th.empty(na, nb, cfg.n_a, device=dev),
+        )
+        check(self.lib.marl_step_forward(
+            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(False).data_ptr(),
+            *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _stream(dev)))
+        return outs
+
+    def debug_buffer(self, name: str, t: int, train: bool = True) -> th.Tensor:
+        """View [R, ld] of a named per-step activation inside the episode workspace (tests)."""
+        off, ld = C.c_int64(0), C.c_int(0)
+        check(self.lib.marl_debug_buffer(C.byref(self.cfg), int(train), name.encode(), t,
+                                         C.byref(off), C.byref(ld)))
+        rows = self.cfg.nb_agents * self.cfg.batch
+        ws = self.episode_ws(train)
+        return ws[off.value: off.value + rows * ld.value].view(rows, ld.value)
+
+    # -- standalone environment kernels ------------------------------------------------
+    def patch_gather(self, img: th.Tensor, pos: th.Tensor, f: int) -> th.Tensor:
+        img = _need(img, th.float32, "img")
+        pos = _need(pos, th.int64, "pos")
+        na, nb, _ = pos.shape
+        _, c, h, w = img.shape
+        obs = th.empty(na, nb, c, f, f, device=img.device)
+        check(self.lib.marl_patch_gather(img.data_ptr(), pos.data_ptr(), obs.data_ptr(), na, nb, c,
+                                         h, w, f, _stream(img.device)))
+        return obs
+
+    def transition(self, pos: th.Tensor, actions: th.Tensor, table: Sequence[Sequence[int]],
+                   sizes: Sequence[int], f: int) -> th.Tensor:
+        pos = _need(pos, th.int64, "pos")
+        actions = _need(actions, th.int64, "actions")
+        out = th.empty_like(pos)
+        flat = (C.c_int32 * (2 * len(table)))(*[v for mv in table for v in mv])
+        rows = pos.shape[0] * pos.shape[1]
+        check(self.lib.marl_transition(pos.data_ptr(), actions.data_ptr(), out.data_ptr(), flat,
+                                       len(table), rows, sizes[0], sizes[1], f,
+                                       _stream(pos.device)))
+        return out

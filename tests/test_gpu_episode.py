@@ -1,0 +1,174 @@
+"""GPU: episode rollout, loss, backward and Adam of the HIP path against the golden
+vectors generated from the real reference and against the CPU oracle.
+
+Tolerances (BASELINE.json north_star): agent positions and sampled action indices
+bit-exact; logits / log-probs / values within 1e-5 fp32; gradients within 1e-4 of the
+tensor's scale."""
+import pytest
+import torch as th
+
+from oracle import marl_oracle as mo
+from tests.util import Golden, model_spec
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def _engine(g, device, ns=None):
+    from marlclassification_amd.engine import HipEngine
+
+    eng = HipEngine(model_spec(g.cfg), device)
+    eng.configure(g.na, g.nb, ns or g.ns, g.img.shape[1:])
+    eng.pack({k: v.to(device) for k, v in g.params.items()})
+    return eng
+
+
+def _forward(eng, g, device, forced=None, train=True):
+    i = g.inp
+    return eng.episode_forward(
+        g.img.to(device), i.pos0.to(device), i.h0.to(device), i.c0.to(device), i.hc0.to(device),
+        i.cc0.to(device), i.q.to(device), None if forced is None else forced.to(device), train)
+
+
+def _maxerr(a, b):
+    return (a.detach().cpu().double() - b.double()).abs().max().item()
+
+
+@pytest.mark.parametrize("tag", ["g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt"])
+@pytest.mark.parametrize("train", [True, False])
+def test_rollout_matches_reference(device, tag, train):
+    g = Golden(tag)
+    eng = _engine(g, device)
+    out = _forward(eng, g, device, train=train)
+    assert th.equal(out.step_actions.cpu(), g.ref("step_actions")), "sampled actions differ"
+    assert th.equal(out.step_pos.cpu(), g.ref("step_pos")), "agent positions differ"
+    errs = {
+        "preds": _maxerr(out.step_preds, g.ref("step_preds")),
+        "logp": _maxerr(out.step_log_probas, g.ref("step_log_probas")),
+        "values": _maxerr(out.step_values, g.ref("step_values")),
+    }
+    assert max(errs.values()) <= ATOL, errs
+
+
+def test_rollout_intermediates_conftest(device):
+    """Localises a mismatch: per-step u_t, h_t, h^_t, msg_t against the oracle trace."""
+    g = Golden("g1_conftest")
+    eng = _engine(g, device)
+    _forward(eng, g, device)
+    tr = mo.run_episode(g.params, g.cfg, g.img, g.inp, g.ns)
+    R = g.na * g.nb
+    for t in range(g.ns):
+        u = eng.debug_buffer("U", t)[:, : g.cfg.nin]
+        assert _maxerr(u, tr.step_u[t].reshape(R, -1)) <= ATOL, ("u", t)
+        h = eng.debug_buffer("H", t + 1)[:, : g.cfg.n_b]
+        assert _maxerr(h, tr.step_h[t].reshape(R, -1)) <= ATOL, ("h", t)
+        hc = eng.debug_buffer("HC", t + 1)[:, : g.cfg.n_a]
+        assert _maxerr(hc, tr.step_hc[t].reshape(R, -1)) <= ATOL, ("hc", t)
+        m = eng.debug_buffer("MSG", t + 1)[:, : g.cfg.n_m]
+        assert _maxerr(m, tr.step_msg[t].reshape(R, -1)) <= ATOL, ("msg", t)
+
+
+def test_rollout_resisc_dims_teacher_forced(device):
+    """RESISC45 dims (16 agents, 16 steps, f=12, 256x256): actions teacher-forced to the
+    reference's so one ulp in a probability cannot fork the trajectory."""
+    g = Golden("g4_resisc_b2")
+    eng = _engine(g, device)
+    out = _forward(eng, g, device, forced=g.ref("step_actions"))
+    assert th.equal(out.step_pos.cpu(), g.ref("step_pos"))
+    errs = {
+        "preds": _maxerr(out.step_preds, g.ref("step_preds")),
+        "logp": _maxerr(out.step_log_probas, g.ref("step_log_probas")),
+        "values": _maxerr(out.step_values, g.ref("step_values")),
+    }
+    assert max(errs.values()) <= ATOL, errs
+    # free-running: the sampled trajectory itself (512 x 16 samples) must agree too
+    free = _forward(eng, g, device)
+    nflip = (free.step_actions.cpu() != g.ref("step_actions")).sum().item()
+    assert nflip == 0, f"{nflip} sampled actions differ from the reference"
+
+
+@pytest.mark.parametrize("tag", ["g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt"])
+def test_loss_and_output_gradients(device, tag):
+    g = Golden(tag)
+    eng = _engine(g, device)
+    out = _forward(eng, g, device)
+    gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+    # oracle: autograd of the restated loss w.r.t. the reference's episode outputs
+    p = g.ref("step_preds").clone().requires_grad_(True)
+    l = g.ref("step_log_probas").clone().requires_grad_(True)
+    v = g.ref("step_values").clone().requires_grad_(True)
+    lo = mo.a2c_loss(p, l, v, g.y, g.gamma)
+    lo.loss.backward()
+    ref_sc = th.stack([lo.loss, lo.path, lo.error, lo.critic]).detach()
+    assert th.allclose(sc.cpu(), ref_sc, rtol=2e-5, atol=2e-5), (sc.cpu(), ref_sc)
+    assert th.allclose(sc.cpu(), g.ref("loss"), rtol=2e-5, atol=2e-5)
+    for a, b, n in ((gp, p.grad, "g_preds"), (gl, l.grad, "g_logp"), (gv, v.grad, "g_values")):
+        scale = b.abs().max().item()
+        assert _maxerr(a, b) <= 2e-5 * scale + 1e-8, n
+
+
+@pytest.mark.parametrize("tag", ["g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt"])
+def test_backward_and_adam_match_reference(device, tag):
+    g = Golden(tag)
+    eng = _engine(g, device)
+    out = _forward(eng, g, device)
+    gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+    grads = {k: th.full_like(v, float("nan"), device=device) for k, v in g.params.items()}
+    eng.episode_backward(gp, gl, gv, grads)
+    bad = {}
+    for k in g.params:
+        ref = g.grad(k)
+        err = _maxerr(grads[k], ref)
+        tol = 1e-4 * ref.abs().max().item() + 1e-7
+        if not err <= tol:
+            bad[k] = (err, tol)
+    assert not bad, bad
+    # one Adam step on the flat buffers (th.optim.Adam defaults, trainer.py:33)
+    names = list(g.params)
+    flat_p = th.cat([g.params[k].flatten() for k in names]).to(device)
+    flat_g = th.cat([grads[k].flatten() for k in names])
+    m, v = th.zeros_like(flat_p), th.zeros_like(flat_p)
+    eng.adam(flat_p, flat_g, m, v, 1, g.lr)
+    ref_after = th.cat([g.after(k).flatten() for k in names])
+    ref_before = th.cat([g.params[k].flatten() for k in names])
+    # the first Adam step moves every weight by ~lr * sign(g); compare the update itself
+    upd, ref_upd = flat_p.cpu() - ref_before, ref_after - ref_before
+    big = th.cat([g.grad(k).flatten() for k in names]).abs() > 1e-6
+    assert (upd[big] - ref_upd[big]).abs().max().item() <= 0.02 * g.lr
+
+
+def test_backward_resisc_dims_gradient_samples(device):
+    g = Golden("g4_resisc_b2")
+    eng = _engine(g, device)
+    out = _forward(eng, g, device, forced=g.ref("step_actions"))
+    gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+    assert th.allclose(sc.cpu(), g.ref("loss"), rtol=5e-5, atol=5e-5), (sc.cpu(), g.ref("loss"))
+    grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+    eng.episode_backward(gp, gl, gv, grads)
+    bad = {}
+    for i, k in enumerate(g.params):
+        idx = th.from_numpy(g.z["gradidx/" + k])
+        ref = th.from_numpy(g.z["gradsample/" + k])
+        got = grads[k].flatten()[idx.to(device)].cpu()
+        scale = float(g.z["grads_abs_sum"][i]) / max(1, g.params[k].numel())  # mean |g|
+        err = (got - ref).abs().max().item()
+        if not err <= 1e-4 * max(ref.abs().max().item(), scale) + 1e-7:
+            bad[k] = (err, ref.abs().max().item())
+    assert not bad, bad
+
+
+def test_step_api_matches_oracle(device):
+    """MultiAgent.act / ModelsWrapper.forward used standalone (marl_step_forward)."""
+    g = Golden("g1_conftest")
+    eng = _engine(g, device, ns=1)
+    i = g.inp
+    sizes = list(g.img.shape[2:])
+    obs = mo.crop_patches(g.img, i.pos0, g.cfg.window)
+    msg = th.randn(g.na, g.nb, g.cfg.n_m, generator=th.Generator().manual_seed(5))
+    npos = mo.normalized_positions(i.pos0, sizes)
+    so = mo.step_forward(g.params, g.cfg, obs, msg, npos, i.h0, i.c0, i.hc0, i.cc0)
+    got = eng.step_forward(*(t.to(device) for t in (obs, msg, npos, i.h0, i.c0, i.hc0, i.cc0)))
+    for a, b, n in zip(got, (so.probs, so.values, so.preds, so.msg, so.h, so.c, so.hc, so.cc),
+                       ("probs", "values", "preds", "msg", "h", "c", "hc", "cc")):
+        assert _maxerr(a, b) <= ATOL, n
