@@ -256,8 +256,8 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
     e.PROBS = b.take(NR * d.nA);
     e.ACT = b.take(NR);
     const size_t steps = train ? (size_t)d.ns : 1;
+    // per-step slices are packed back to back so that [Ns][rows][ld] is also [Ns*rows][ld]
     auto per = [&](SBuf& s, size_t n) {
-        n = (n + 63) & ~(size_t)63;
         s.off = b.take(n * steps);
         s.stride = train ? n : 0;
     };

@@ -35,6 +35,12 @@ def _maxerr(a, b):
     return (a.detach().cpu().double() - b.double()).abs().max().item()
 
 
+def _relerr(a, b):
+    """max |a - b| in units of max(1, max|b|): 1e-5 absolute for O(1) logits, 1e-5 of the
+    tensor's scale for the trained checkpoint whose logits reach ~15."""
+    return _maxerr(a, b) / max(1.0, b.abs().max().item())
+
+
 @pytest.mark.parametrize("tag", ["g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt"])
 @pytest.mark.parametrize("train", [True, False])
 def test_rollout_matches_reference(device, tag, train):
@@ -44,9 +50,9 @@ def test_rollout_matches_reference(device, tag, train):
     assert th.equal(out.step_actions.cpu(), g.ref("step_actions")), "sampled actions differ"
     assert th.equal(out.step_pos.cpu(), g.ref("step_pos")), "agent positions differ"
     errs = {
-        "preds": _maxerr(out.step_preds, g.ref("step_preds")),
-        "logp": _maxerr(out.step_log_probas, g.ref("step_log_probas")),
-        "values": _maxerr(out.step_values, g.ref("step_values")),
+        "preds": _relerr(out.step_preds, g.ref("step_preds")),
+        "logp": _relerr(out.step_log_probas, g.ref("step_log_probas")),
+        "values": _relerr(out.step_values, g.ref("step_values")),
     }
     assert max(errs.values()) <= ATOL, errs
 
@@ -122,8 +128,8 @@ def test_backward_and_adam_match_reference(device, tag):
         err = _maxerr(grads[k], ref)
         tol = 1e-4 * ref.abs().max().item() + 1e-7
         if not err <= tol:
-            bad[k] = (err, tol)
-    assert not bad, bad
+            bad[k.replace("_ModelsWrapper__", "")] = "%.2e/%.2e" % (err, ref.abs().max().item())
+    assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
     # one Adam step on the flat buffers (th.optim.Adam defaults, trainer.py:33)
     names = list(g.params)
     flat_p = th.cat([g.params[k].flatten() for k in names]).to(device)

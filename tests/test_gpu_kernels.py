@@ -42,8 +42,10 @@ def test_gemm_nt(device, m, n, k, acc):
     ldc = n + 3
     cd = th.zeros(m, ldc, device=device)
     cd[:, :n] = c0.to(device)
+    bias_d = bias.to(device)
     check(lib.marl_gemm_nt(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1],
-                           bias.to(device).data_ptr(), cd.data_ptr(), ldc, m, n, k, acc, None))
+                           bias_d.data_ptr(), cd.data_ptr(), ldc, m, n, k, acc, None))
+    th.cuda.synchronize()
     ref = a.double() @ b.double().t() + bias.double() + (c0.double() if acc else 0)
     err = (cd[:, :n].cpu().double() - ref).abs().max().item()
     scale = ref.abs().max().item()
@@ -58,8 +60,10 @@ def test_gemm_nt_is_transpose_detecting(device):
     a = th.eye(m, k)
     b = th.arange(n * k, dtype=th.float32).view(n, k) / 7.0
     cd = th.zeros(m, n, device=device)
-    check(lib.marl_gemm_nt(a.to(device).data_ptr(), k, b.to(device).data_ptr(), k, None,
-                           cd.data_ptr(), n, m, n, k, 0, None))
+    ad, bd = a.to(device), b.to(device)
+    check(lib.marl_gemm_nt(ad.data_ptr(), k, bd.data_ptr(), k, None, cd.data_ptr(), n, m, n, k, 0,
+                           None))
+    th.cuda.synchronize()
     assert th.equal(cd.cpu(), b.t().contiguous()[:m])
 
 
@@ -97,9 +101,10 @@ def test_ln_silu_fwd(device, m, n):
     zd = _padded(z.to(device), _p4(n))
     out = th.zeros(m, _p4(n) + 4, device=device)
     stats = th.zeros(m, 2, device=device)
-    check(lib.marl_ln_silu_fwd(zd.data_ptr(), zd.shape[1], gamma.to(device).data_ptr(),
-                               beta.to(device).data_ptr(), out.data_ptr(), out.shape[1],
-                               stats.data_ptr(), m, n, None))
+    gd, bd = gamma.to(device), beta.to(device)
+    check(lib.marl_ln_silu_fwd(zd.data_ptr(), zd.shape[1], gd.data_ptr(), bd.data_ptr(),
+                               out.data_ptr(), out.shape[1], stats.data_ptr(), m, n, None))
+    th.cuda.synchronize()
     ref = F.silu(F.layer_norm(z, (n,), gamma, beta, 1e-5))
     assert th.allclose(out[:, :n].cpu(), ref, rtol=1e-5, atol=2e-6)
     assert th.equal(out[:, n:].cpu(), th.zeros(m, out.shape[1] - n))
