@@ -174,6 +174,13 @@ size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows);
 int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta,
                      float* out, int ldo, float* stats, int m, int n, void* stream);
 
+/* Measurement hook (bench.py roofline): time every launch of one kernel class with HIP
+ * events recorded on the launch stream.  class 0 = fused LSTM-cell GEMM, 1 = plain NT GEMM,
+ * 2 = row-contraction (weight-gradient) GEMM.  marl_profile_end synchronises those events
+ * and returns the summed kernel time and the number of launches seen. */
+int marl_profile_begin(int kernel_class, int max_launches);
+int marl_profile_end(double* total_ms, int* launches);
+
 /* test hook: float offset and leading dimension of a named per-step activation inside
  * episode_ws ("U","H","C","HC","CC","MSG","PROBS","COLS0","Z0","GB","DU","DH","DHC"). */
 int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t,

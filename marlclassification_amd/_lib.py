@@ -64,7 +64,8 @@ EXPORTS = (
     "marl_abi_version marl_last_error marl_param_numel marl_workspace_sizes marl_pack_weights "
     "marl_patch_gather marl_transition marl_episode_forward marl_episode_backward "
     "marl_a2c_loss_fwd_bwd marl_adam_step marl_step_forward marl_gemm_nt marl_gemm_tn "
-    "marl_gemm_tn_scratch marl_ln_silu_fwd marl_debug_buffer"
+    "marl_gemm_tn_scratch marl_ln_silu_fwd marl_debug_buffer "
+    "marl_profile_begin marl_profile_end"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -94,6 +95,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_gemm_tn_scratch.restype = _sz
     lib.marl_gemm_tn_scratch.argtypes = [_i, _i, _i64]
     lib.marl_ln_silu_fwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]
+    lib.marl_profile_begin.argtypes = [_i, _i]
+    lib.marl_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(_i)]
     lib.marl_debug_buffer.argtypes = [_cfgp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]
     for name in EXPORTS:
         fn = getattr(lib, name)

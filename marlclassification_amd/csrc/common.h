@@ -76,6 +76,9 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st);
 // LSTM cell: gates = seg products + bias over 4*n_units rows of B, then the cell update.
 int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st);
 
+int profile_begin(int cls, int max_launches);
+int profile_end(double* total_ms, int* launches);
+
 // C[NI,NJ] = sum_r A[r,i] * B[r,j]  (weight gradients; contraction over rows).
 size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows);
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
@@ -88,7 +91,7 @@ int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float*
                        int ldo, float* stats, int64_t m, int n, hipStream_t st);
 // dz = d(loss)/d(z) from da = d(loss)/d(silu out); dgamma/dbeta partial sums are written
 // to part[nblk][2][n]; returns nblk through *nblk_out.
-int ln_bwd_blocks(int64_t m);
+int ln_bwd_blocks(int64_t m, int n);
 int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
                        const float* gamma, const float* beta, float* dz, int lddz, float* part,
                        int64_t m, int n, hipStream_t st);
@@ -108,7 +111,7 @@ int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float
 int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
                        int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
                        hipStream_t st);
-int gn_bwd_blocks(int64_t rows);
+int gn_bwd_blocks(int64_t rows, int C);
 int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
                        const float* stats, const float* gamma, const float* beta, float* dz,
                        float* part, int64_t rows, int P, int C, int G, hipStream_t st);

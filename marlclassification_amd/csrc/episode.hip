@@ -334,13 +334,13 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
             tns = v > tns ? v : tns;
         };
         const int64_t nr = d.NR, r = d.R;
-        upd_part(ln_bwd_blocks(nr), d.nlb);
-        upd_part(ln_bwd_blocks(nr), d.nla);
-        upd_part(ln_bwd_blocks(nr), d.n_d);
-        upd_part(ln_bwd_blocks(r), d.nm2);
-        upd_part(ln_bwd_blocks(r), d.n_mo);
-        upd_part(ln_bwd_blocks(r), d.n_m);
-        for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr), d.ch[l + 1]);
+        upd_part(ln_bwd_blocks(nr, d.nlb), d.nlb);
+        upd_part(ln_bwd_blocks(nr, d.nla), d.nla);
+        upd_part(ln_bwd_blocks(nr, d.n_d), d.n_d);
+        upd_part(ln_bwd_blocks(r, d.nm2), d.nm2);
+        upd_part(ln_bwd_blocks(r, d.n_mo), d.n_mo);
+        upd_part(ln_bwd_blocks(r, d.n_m), d.n_m);
+        for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr, d.ch[l + 1]), d.ch[l + 1]);
         int widths[] = {d.nC, d.nlb, d.nla, 4, d.nA, d.n_mo, d.nm2, d.n_m, 4 * d.n_b, 4 * d.n_a, d.n_d};
         for (int wv : widths) upd_cs(nr, wv);
         for (int l = 0; l < d.L; ++l) upd_cs(nr * d.P[l], d.ch[l + 1]);
@@ -699,7 +699,7 @@ static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, co
     }
     MARL_TRY(launch_ln_silu_bwd(da, ldda, z, ldz, stats, c.wp(pw), c.wp(pb), dz, lddz,
                                 c.at(c.e.PART), rows, n, c.st));
-    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows), n, grads[pw], grads[pb], acc,
+    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], acc,
                                 c.st);
 }
 
@@ -869,7 +869,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             MARL_TRY(launch_gn_silu_bwd(da, ldda, chw, c.at(c.e.Z[l], 0), c.at(c.e.GST[l], 0),
                                         c.wp(4 * l + 2), c.wp(4 * l + 3), dz, c.at(c.e.PART), NR,
                                         d.P[l], co, d.grp[l], st));
-            MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR), co, grads[4 * l + 2],
+            MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR, co), co, grads[4 * l + 2],
                                           grads[4 * l + 3], 0, st));
             MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows));
             MARL_TRY(csum(c, dz, co, rows, co, grads[4 * l + 1]));
@@ -1142,6 +1142,12 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
     set_error("unknown debug buffer %s", name);
     return MARL_EINVAL;
 }
+
+int marl_profile_begin(int kernel_class, int max_launches) {
+    if (kernel_class < 0 || kernel_class > 2 || max_launches < 1) return MARL_EINVAL;
+    return profile_begin(kernel_class, max_launches);
+}
+int marl_profile_end(double* total_ms, int* launches) { return profile_end(total_ms, launches); }
 
 // ---- kernel-level entry points -------------------------------------------------------
 int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* bias, float* c,

@@ -330,9 +330,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int64_t spl
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)NI * NJ) return;
     const int i = (int)(idx / NJ), j = (int)(idx % NJ);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(size_t)z * split_stride + idx];
-    c[(size_t)i * ldc + j] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {  // 4 independent loads in flight, fixed order
+        s0 += part[(size_t)z * split_stride + idx];
+        s1 += part[(size_t)(z + 1) * split_stride + idx];
+        s2 += part[(size_t)(z + 2) * split_stride + idx];
+        s3 += part[(size_t)(z + 3) * split_stride + idx];
+    }
+    for (; z < splits; ++z) s0 += part[(size_t)z * split_stride + idx];
+    c[(size_t)i * ldc + j] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------
@@ -356,6 +363,9 @@ void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb,
     p.seg[1] = GemmSeg{a, b, lda, ldb, k};
     p.nseg = 2;
 }
+
+static void prof_before(int cls, hipStream_t st);
+static void prof_after(int cls, hipStream_t st);
 
 static int check_prob(const GemmProb& p) {
     for (int s = 0; s < p.nseg; ++s) {
@@ -386,6 +396,7 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
         max_n = batch.p[i].n > max_n ? batch.p[i].n : max_n;
         blocks128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 128);
     }
+    prof_before(1, st);
     if (blocks128 >= 256 && max_n >= 96) {
         dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, batch);
@@ -393,7 +404,56 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
         dim3 grid((unsigned)cdiv(max_m, 64), (unsigned)cdiv(max_n, 64), (unsigned)batch.count);
         hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, batch);
     }
+    prof_after(1, st);
     MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// optional per-launch timing of one kernel class with HIP events recorded on the launch
+// stream (bench.py's roofline figure).  class 0 = fused LSTM GEMM, 1 = plain NT GEMM,
+// 2 = TN GEMM.  Off by default: no events are created or recorded.
+// ---------------------------------------------------------------------------
+static int g_prof_class = -1;
+static int g_prof_cap = 0, g_prof_n = 0;
+static hipEvent_t* g_prof_ev = nullptr;  // [2 * cap]
+
+static void prof_before(int cls, hipStream_t st) {
+    if (cls == g_prof_class && g_prof_n < g_prof_cap) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], st);
+}
+static void prof_after(int cls, hipStream_t st) {
+    if (cls == g_prof_class && g_prof_n < g_prof_cap) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);
+        ++g_prof_n;
+    }
+}
+
+int profile_begin(int cls, int max_launches) {
+    if (g_prof_ev) return MARL_EINVAL;
+    g_prof_ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) MARL_HIP_CHECK(hipEventCreate(&g_prof_ev[i]));
+    g_prof_cap = max_launches;
+    g_prof_n = 0;
+    g_prof_class = cls;
+    return MARL_OK;
+}
+
+int profile_end(double* total_ms, int* launches) {
+    if (!g_prof_ev) return MARL_EINVAL;
+    double tot = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        MARL_HIP_CHECK(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        MARL_HIP_CHECK(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (int i = 0; i < 2 * g_prof_cap; ++i) (void)hipEventDestroy(g_prof_ev[i]);
+    delete[] g_prof_ev;
+    g_prof_ev = nullptr;
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = g_prof_n;
+    g_prof_class = -1;
+    g_prof_cap = g_prof_n = 0;
     return MARL_OK;
 }
 
@@ -408,7 +468,9 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
         max_n = p.n > max_n ? p.n : max_n;
     }
     dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
+    prof_before(0, st);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 1, true>), grid, dim3(256), 0, st, batch);
+    prof_after(0, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -462,12 +524,14 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         stride = (int64_t)ni * nj;
     }
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
+    prof_before(2, st);
     if (p.bm == 128)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
                            out, ldo, stride, ni, nj, rows, p.rows_per_split);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
                            out, ldo, stride, ni, nj, rows, p.rows_per_split);
+    prof_after(2, st);
     MARL_LAUNCH_CHECK();
     if (p.splits > 1) {
         const int64_t n = (int64_t)ni * nj;

@@ -150,22 +150,31 @@ __global__ __launch_bounds__(256) void loss_returns_kernel(const float* __restri
     }
 }
 
-__global__ void loss_stats_kernel(const double* __restrict__ part, int nblocks,
-                                  const float* __restrict__ err, int64_t nerr,
-                                  double* __restrict__ part_err, double* __restrict__ adv_stats,
-                                  double n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = 0; i < nblocks; ++i) {
-            s1 += part[2 * i];
-            s2 += part[2 * i + 1];
-        }
+// one 256-thread block; strided partial sums + fixed-order tree -> deterministic
+__global__ __launch_bounds__(256) void loss_stats_kernel(
+    const double* __restrict__ part, int nblocks, const float* __restrict__ err, int64_t nerr,
+    double* __restrict__ part_err, double* __restrict__ adv_stats, double n) {
+    __shared__ double sh[3][256];
+    double s1 = 0.0, s2 = 0.0, e = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        s1 += part[2 * i];
+        s2 += part[2 * i + 1];
+    }
+    for (int64_t i = threadIdx.x; i < nerr; i += 256) e += (double)err[i];
+    sh[0][threadIdx.x] = s1;
+    sh[1][threadIdx.x] = s2;
+    sh[2][threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
         adv_stats[0] = n;
-        adv_stats[1] = s1;
-        adv_stats[2] = s2;
-        double e = 0.0;
-        for (int64_t i = 0; i < nerr; ++i) e += (double)err[i];
-        part_err[0] = e;
+        adv_stats[1] = sh[0][0];
+        adv_stats[2] = sh[1][0];
+        part_err[0] = sh[2][0];
     }
 }
 
@@ -209,15 +218,28 @@ __global__ __launch_bounds__(256) void loss_grads_kernel(
 }
 
 // scalars = {loss, path.sum(0).mean(), error.mean(), critic.sum(0).mean()} (trainer.py:111,119-122)
-__global__ void loss_final_kernel(const double* __restrict__ part, int nblocks,
-                                  const double* __restrict__ part_err, float* __restrict__ scalars,
-                                  int ns, int nb, int64_t R) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double p = 0.0, c = 0.0;
-        for (int i = 0; i < nblocks; ++i) {
-            p += part[2 * i];
-            c += part[2 * i + 1];
+__global__ __launch_bounds__(256) void loss_final_kernel(
+    const double* __restrict__ part, int nblocks, const double* __restrict__ part_err,
+    float* __restrict__ scalars, int ns, int nb, int64_t R) {
+    __shared__ double sh[2][256];
+    double p = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        p += part[2 * i];
+        c += part[2 * i + 1];
+    }
+    sh[0][threadIdx.x] = p;
+    sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p = sh[0][0];
+        c = sh[1][0];
         const double path = p / (double)R, critic = c / (double)R;
         const double esum = part_err[0];
         scalars[0] = (float)(path + esum / (double)nb + critic);
@@ -247,7 +269,7 @@ int launch_loss(const LossArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(loss_returns_kernel, dim3((unsigned)L.blocksC), dim3(256), 0, st, L.rew,
                            a.values, L.ret, L.adv, L.part_adv, a.ns, R, a.gamma);
         MARL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(64), 0, st, L.part_adv, L.blocksC,
+        hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(256), 0, st, L.part_adv, L.blocksC,
                            L.err, (int64_t)a.ns * a.nb, L.part_err, stats, (double)NR);
         MARL_LAUNCH_CHECK();
     }
@@ -255,7 +277,7 @@ int launch_loss(const LossArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(loss_grads_kernel, dim3((unsigned)L.blocksE), dim3(256), 0, st, a.logp,
                            a.values, L.ret, L.adv, stats, a.g_logp, a.g_values, L.part_loss, NR, R);
         MARL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, L.part_loss, L.blocksE,
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, L.part_loss, L.blocksE,
                            L.part_err, a.scalars, a.ns, a.nb, R);
         MARL_LAUNCH_CHECK();
     }

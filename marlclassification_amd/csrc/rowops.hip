@@ -77,23 +77,30 @@ int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float*
     return MARL_OK;
 }
 
-static int ln_rows_per_wave(int64_t m) {
-    int64_t r = cdiv(m, 4 * 1024);
+// Backward launches use wide workgroups (up to 16 waves, one row at a time per wave) so that
+// thousands of waves are in flight while only ~256 partial dgamma/dbeta slabs are produced.
+static int bwd_waves(int n) { return n <= 512 ? 16 : (n <= 1024 ? 8 : 4); }
+static int bwd_rows_per_wave(int64_t m, int waves) {
+    int64_t r = cdiv(m, (int64_t)waves * 256);
     if (r < 1) r = 1;
-    if (r > 16) r = 16;
+    if (r > 64) r = 64;
     return (int)r;
 }
-int ln_bwd_blocks(int64_t m) { return (int)cdiv(m, 4 * ln_rows_per_wave(m)); }
+int ln_bwd_blocks(int64_t m, int n) {
+    const int w = bwd_waves(n);
+    return (int)cdiv(m, (int64_t)w * bwd_rows_per_wave(m, w));
+}
 
 // part[blk][0][n] = sum_rows dy * xhat (dgamma), part[blk][1][n] = sum_rows dy (dbeta)
-__global__ __launch_bounds__(256) void ln_silu_bwd_kernel(
+__global__ __launch_bounds__(1024) void ln_silu_bwd_kernel(
     const float* __restrict__ da, int ldda, const float* __restrict__ z, int ldz,
     const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ dz, int lddz, float* __restrict__ part,
     int64_t m, int n, int rpw) {
-    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [4][2][n]
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [waves][2][n]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
     float* ga = sacc + (size_t)wave * 2 * n;
     float* gb = ga + n;
     for (int c = lane; c < n; c += 64) {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_silu_bwd_kernel(
         gb[c] = 0.f;
     }
     for (int rr = 0; rr < rpw; ++rr) {
-        const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + rr;
+        const int64_t row = ((int64_t)blockIdx.x * nwaves + wave) * rpw + rr;
         if (row >= m) break;
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
         const float* zr = z + row * ldz;
@@ -129,8 +136,11 @@ __global__ __launch_bounds__(256) void ln_silu_bwd_kernel(
     }
     __syncthreads();
     float* p = part + (size_t)blockIdx.x * 2 * n;
-    for (int c = threadIdx.x; c < 2 * n; c += 256)
-        p[c] = ((sacc[c] + sacc[2 * n + c]) + sacc[4 * n + c]) + sacc[6 * n + c];
+    for (int c = threadIdx.x; c < 2 * n; c += blockDim.x) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sacc[(size_t)w * 2 * n + c];
+        p[c] = t;
+    }
 }
 
 int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
@@ -141,10 +151,11 @@ int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const
         set_error("LayerNorm width %d > 2048 unsupported", n);
         return MARL_ELIMIT;
     }
-    const int rpw = ln_rows_per_wave(m);
-    hipLaunchKernelGGL(ln_silu_bwd_kernel, dim3((unsigned)ln_bwd_blocks(m)), dim3(256),
-                       (size_t)8 * n * sizeof(float), st, da, ldda, z, ldz, stats, gamma, beta, dz,
-                       lddz, part, m, n, rpw);
+    const int w = bwd_waves(n);
+    const int rpw = bwd_rows_per_wave(m, w);
+    hipLaunchKernelGGL(ln_silu_bwd_kernel, dim3((unsigned)ln_bwd_blocks(m, n)), dim3(64 * w),
+                       (size_t)w * 2 * n * sizeof(float), st, da, ldda, z, ldz, stats, gamma, beta,
+                       dz, lddz, part, m, n, rpw);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -159,8 +170,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < n)
-        for (int64_t p = grp; p < nparts; p += 4) s += part[p * stride + c];
+    if (c < n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t p = grp;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += part[p * stride + c];
+            s1 += part[(p + 4) * stride + c];
+            s2 += part[(p + 8) * stride + c];
+            s3 += part[(p + 12) * stride + c];
+        }
+        for (; p < nparts; p += 4) s0 += part[p * stride + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sh[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < n) {
@@ -188,8 +209,18 @@ __global__ __launch_bounds__(256) void reduce_affine_kernel(const float* __restr
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;  // column in [0, 2n): gamma then beta
     float s = 0.f;
-    if (c < 2 * n)
-        for (int64_t p = grp; p < nparts; p += 4) s += part[p * 2 * n + c];
+    if (c < 2 * n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t p = grp;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += part[p * 2 * n + c];
+            s1 += part[(p + 4) * 2 * n + c];
+            s2 += part[(p + 8) * 2 * n + c];
+            s3 += part[(p + 12) * 2 * n + c];
+        }
+        for (; p < nparts; p += 4) s0 += part[p * 2 * n + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sh[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && c < 2 * n) {
@@ -301,24 +332,22 @@ int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, fl
     return MARL_OK;
 }
 
-static int gn_rows_per_wave(int64_t rows) {
-    int64_t r = cdiv(rows, 4 * 2048);
-    if (r < 1) r = 1;
-    if (r > 64) r = 64;
-    return (int)r;
+int gn_bwd_blocks(int64_t rows, int C) {
+    const int w = bwd_waves(C);
+    return (int)cdiv(rows, (int64_t)w * bwd_rows_per_wave(rows, w));
 }
-int gn_bwd_blocks(int64_t rows) { return (int)cdiv(rows, 4 * gn_rows_per_wave(rows)); }
 
 // Lane (cc, pslot) owns channel g*Cg+cc and walks positions pslot, pslot+64/Cg, ... so the
 // per-channel dgamma/dbeta sums have a single owner (no LDS races, fixed order).
-__global__ __launch_bounds__(256) void gn_silu_bwd_kernel(
+__global__ __launch_bounds__(1024) void gn_silu_bwd_kernel(
     const float* __restrict__ da, int64_t ldda, int da_chw, const float* __restrict__ z,
     const float* __restrict__ stats, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ dz, float* __restrict__ part,
     int64_t rows, int P, int C, int G, int rpw) {
-    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [4][2][C]
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [waves][2][C]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
     float* ga = sacc + (size_t)wave * 2 * C;
     float* gb = ga + C;
     for (int c = lane; c < C; c += 64) {
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(
     const int cc = lane % Cg, pslot = lane / Cg, pstep = 64 / Cg;
     const float inv_cnt = 1.0f / (float)(P * Cg);
     for (int rr = 0; rr < rpw; ++rr) {
-        const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + rr;
+        const int64_t row = ((int64_t)blockIdx.x * nwaves + wave) * rpw + rr;
         if (row >= rows) break;
         const float* zr = z + row * (int64_t)P * C;
         const float* dar = da + row * ldda;
@@ -369,8 +398,11 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(
     }
     __syncthreads();
     float* p = part + (size_t)blockIdx.x * 2 * C;
-    for (int c = threadIdx.x; c < 2 * C; c += 256)
-        p[c] = ((sacc[c] + sacc[2 * C + c]) + sacc[4 * C + c]) + sacc[6 * C + c];
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sacc[(size_t)w * 2 * C + c];
+        p[c] = t;
+    }
 }
 
 int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
@@ -382,10 +414,11 @@ int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z
         set_error("GroupNorm backward needs channels/group a power of two <= 64 (got %d)", Cg);
         return MARL_ELIMIT;
     }
-    const int rpw = gn_rows_per_wave(rows);
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3((unsigned)gn_bwd_blocks(rows)), dim3(256),
-                       (size_t)8 * C * sizeof(float), st, da, ldda, da_chw, z, stats, gamma, beta,
-                       dz, part, rows, P, C, G, rpw);
+    const int w = bwd_waves(C);
+    const int rpw = bwd_rows_per_wave(rows, w);
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3((unsigned)gn_bwd_blocks(rows, C)), dim3(64 * w),
+                       (size_t)w * 2 * C * sizeof(float), st, da, ldda, da_chw, z, stats, gamma,
+                       beta, dz, part, rows, P, C, G, rpw);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

@@ -1,0 +1,142 @@
+"""One A2C training iteration entirely on the HIP path (the body of the reference's
+``Trainer.train_epoch`` loop, training/trainer.py:66-116): rollout -> loss + output
+gradients -> backward through the episode -> [gradient all-reduce] -> Adam -> re-pack.
+
+Parameters live in ONE flat fp32 buffer (the model's ``nn.Parameter``s are views into it),
+gradients in a second one, so that Adam is a single kernel and data parallelism is a single
+all-reduce (parallel.py).  No host synchronisation happens inside ``iteration``.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch as th
+
+from .engine import EpisodeTensors, HipEngine, ModelSpec
+
+
+@dataclass
+class EpisodeDraws:
+    """The reference's random draws for one episode, in its draw order:
+    positions (environment.py:33-43), h, c, h^, c^ (models.py:148-159), then one Exp(1)
+    tensor per step (``th.multinomial`` == argmax(p / q), agent.py:53-55)."""
+
+    pos0: th.Tensor
+    h0: th.Tensor
+    c0: th.Tensor
+    hc0: th.Tensor
+    cc0: th.Tensor
+    noise: th.Tensor
+
+
+def draw_episode(spec: ModelSpec, na: int, nb: int, ns: int, sizes, device,
+                 generator: Optional[th.Generator] = None) -> EpisodeDraws:
+    """Device-side draws (torch's Philox generator: RNG plumbing, not compute)."""
+    f = spec.window
+    pos0 = th.stack(
+        [th.randint(int(s) - f, (na, nb), device=device, generator=generator) for s in sizes],
+        dim=-1,
+    )
+    h0 = th.randn(na, nb, spec.n_b, device=device, generator=generator)
+    c0 = th.randn(na, nb, spec.n_b, device=device, generator=generator)
+    hc0 = th.randn(na, nb, spec.n_a, device=device, generator=generator)
+    cc0 = th.randn(na, nb, spec.n_a, device=device, generator=generator)
+    noise = th.empty(ns, na, nb, len(spec.actions), device=device).exponential_(
+        1.0, generator=generator
+    )
+    return EpisodeDraws(pos0, h0, c0, hc0, cc0, noise)
+
+
+class FlatParams:
+    """Flat fp32 parameter / gradient / Adam-moment buffers with per-tensor views."""
+
+    def __init__(self, shapes: Dict[str, Tuple[int, ...]], device: th.device) -> None:
+        self.names: List[str] = list(shapes)
+        self.shapes = dict(shapes)
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for k, s in shapes.items():
+            self.offsets[k] = off
+            n = 1
+            for d in s:
+                n *= d
+            # 16-byte aligned slices so every tensor can be read with 128-bit loads
+            off += (n + 3) & ~3
+        self.numel = off
+        self.params = th.zeros(off, device=device)
+        self.grads = th.zeros(off, device=device)
+        self.exp_avg = th.zeros(off, device=device)
+        self.exp_avg_sq = th.zeros(off, device=device)
+        self.step = 0
+
+    def _views(self, flat: th.Tensor) -> Dict[str, th.Tensor]:
+        out = {}
+        for k, s in self.shapes.items():
+            n = 1
+            for d in s:
+                n *= d
+            out[k] = flat[self.offsets[k]: self.offsets[k] + n].view(s)
+        return out
+
+    def param_views(self) -> Dict[str, th.Tensor]:
+        return self._views(self.params)
+
+    def grad_views(self) -> Dict[str, th.Tensor]:
+        return self._views(self.grads)
+
+    def load(self, tensors: Dict[str, th.Tensor]) -> None:
+        views = self.param_views()
+        with th.no_grad():
+            for k in self.names:
+                views[k].copy_(tensors[k])
+
+
+class FusedA2C:
+    """rollout + loss + backward + Adam on one GPU; ``allreduce`` hooks in data parallelism."""
+
+    def __init__(self, engine: HipEngine, flat: FlatParams, lr: float, gamma: float,
+                 allreduce: Optional[Callable[[th.Tensor], float]] = None) -> None:
+        self.engine = engine
+        self.flat = flat
+        self.lr = lr
+        self.gamma = gamma
+        self.allreduce = allreduce
+        self._pviews = flat.param_views()
+        self._gviews = flat.grad_views()
+        self._loss_bufs = None
+        self._packed = False
+
+    def pack(self) -> None:
+        self.engine.pack(self._pviews)
+        self._packed = True
+
+    def rollout(self, img: th.Tensor, draws: EpisodeDraws, train: bool,
+                forced_actions: Optional[th.Tensor] = None) -> EpisodeTensors:
+        if not self._packed:
+            self.pack()
+        return self.engine.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0,
+                                           draws.cc0, draws.noise, forced_actions, train)
+
+    def iteration(self, img: th.Tensor, y: th.Tensor, draws: EpisodeDraws) -> Tuple[EpisodeTensors, th.Tensor]:
+        """Returns the episode outputs and the device tensor {loss, path, error, critic}."""
+        eng = self.engine
+        out = self.rollout(img, draws, True)
+        if self._loss_bufs is None or self._loss_bufs[0].shape != out.step_preds.shape:
+            dev = eng.device
+            self._loss_bufs = (
+                th.empty_like(out.step_preds), th.empty_like(out.step_log_probas),
+                th.empty_like(out.step_values), th.zeros(4, device=dev),
+                th.zeros(3, dtype=th.float64, device=dev),
+            )
+        gp, gl, gv, scalars, _ = eng.a2c_loss(out, y, self.gamma, 0, self._loss_bufs)
+        eng.episode_backward(gp, gl, gv, self._gviews)
+        scale = 1.0
+        if self.allreduce is not None:
+            scale = self.allreduce(self.flat.grads)
+        self.flat.step += 1
+        eng.adam(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq,
+                 self.flat.step, self.lr, grad_scale=scale)
+        self.pack()
+        return out, scalars
