@@ -161,7 +161,13 @@ int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* epis
                       const float* obs, const float* msg, const float* norm_pos,
                       const float* h, const float* c, const float* hc, const float* cc,
                       float* probs, float* values, float* preds, float* new_msg,
-                      float* h_out, float* c_out, float* hc_out, float* cc_out, void* stream);
+                      float* h_out, float* c_out, float* hc_out, float* cc_out,
+                      const float* noise, int64_t* actions_out, float* logp_out, void* stream);
+/* (noise [R,nA] ~ Exp(1), actions_out int64 [R], logp_out [R]: optional - when all three are
+ * given the call also samples the action and its log-probability, core/agent.py:53-61.) */
+
+/* Environment.normalized_positions (core/environment.py:74-81): out[r,d] = pos[r,d] / size_d. */
+int marl_normalize_positions(const int64_t* pos, float* out, int rows, int h, int w, void* stream);
 
 /* ---- kernel-level entry points (used by tests/ and profiling; same kernels) ---- */
 /* C[M,N] (+)= A[M,K] * B[N,K]^T + bias ; lda/ldb multiples of 4, 16-byte aligned. */

@@ -65,7 +65,7 @@ EXPORTS = (
     "marl_patch_gather marl_transition marl_episode_forward marl_episode_backward "
     "marl_a2c_loss_fwd_bwd marl_adam_step marl_step_forward marl_gemm_nt marl_gemm_tn "
     "marl_gemm_tn_scratch marl_ln_silu_fwd marl_debug_buffer "
-    "marl_profile_begin marl_profile_end"
+    "marl_profile_begin marl_profile_end marl_normalize_positions"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -89,7 +89,8 @@ def _declare(lib: C.CDLL) -> None:
         [_cfgp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
     )
     lib.marl_adam_step.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _vp]
-    lib.marl_step_forward.argtypes = [_cfgp, _vp, _vp] + [_vp] * 15 + [_vp]
+    lib.marl_step_forward.argtypes = [_cfgp, _vp, _vp] + [_vp] * 15 + [_vp] * 3 + [_vp]
+    lib.marl_normalize_positions.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     lib.marl_gemm_nt.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.marl_gemm_tn.argtypes = [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i64, _vp, _sz, _vp]
     lib.marl_gemm_tn_scratch.restype = _sz

@@ -1081,7 +1081,8 @@ int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* epis
                       const float* obs, const float* msg, const float* norm_pos, const float* h,
                       const float* cc_, const float* hc, const float* cca, float* probs,
                       float* values, float* preds, float* new_msg, float* h_out, float* c_out,
-                      float* hc_out, float* cc_out, void* stream) {
+                      float* hc_out, float* cc_out, const float* noise, int64_t* actions_out,
+                      float* logp_out, void* stream) {
     Ctx c;
     MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 0, stream, c));
     if (!obs || !msg || !norm_pos || !h || !cc_ || !hc || !cca || !probs || !values || !preds ||
@@ -1098,7 +1099,13 @@ int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* epis
     SampleArgs a;
     fill_sample_args(c, cfg, 0, a);
     a.probs = probs;
-    a.step_logp = nullptr;  // probabilities only
+    if (noise && actions_out && logp_out) {  // also sample (positions of the scratch slot are unused)
+        a.noise = noise;
+        a.step_actions = actions_out;
+        a.step_logp = logp_out;
+    } else {
+        a.step_logp = nullptr;  // probabilities only
+    }
     MARL_TRY(launch_sample(a, c.st));
     MARL_TRY(heads_batched(c, 0, d.R, values, preds));
     MARL_TRY(launch_copy2d(c.MSGs(1), d.ld_nm, new_msg, d.n_m, d.R, d.n_m, c.st));
@@ -1141,6 +1148,29 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
     }
     set_error("unknown debug buffer %s", name);
     return MARL_EINVAL;
+}
+
+}  // extern "C"
+namespace marl {
+__global__ void normalize_positions_kernel(const int64_t* __restrict__ pos, float* __restrict__ out,
+                                           int rows, int H, int W) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    out[r * 2] = (float)pos[r * 2] / (float)H;
+    out[r * 2 + 1] = (float)pos[r * 2 + 1] / (float)W;
+}
+}  // namespace marl
+extern "C" {
+
+int marl_normalize_positions(const int64_t* pos, float* out, int rows, int h, int w, void* stream) {
+    if (!pos || !out || rows < 1 || h < 1 || w < 1) {
+        set_error("normalize_positions: bad argument");
+        return MARL_EINVAL;
+    }
+    hipLaunchKernelGGL(normalize_positions_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pos, out, rows, h, w);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
 }
 
 int marl_profile_begin(int kernel_class, int max_launches) {

@@ -294,9 +294,10 @@ class HipEngine:
 
     def step_forward(
         self, obs: th.Tensor, msg: th.Tensor, norm_pos: th.Tensor, h: th.Tensor, c: th.Tensor,
-        hc: th.Tensor, cc: th.Tensor,
+        hc: th.Tensor, cc: th.Tensor, noise: Optional[th.Tensor] = None,
     ) -> Tuple[th.Tensor, ...]:
-        """marl_step_forward: (probs, values, preds, new_msg, h, c, hc, cc) in [Na,Nb,..]."""
+        """marl_step_forward: (probs, values, preds, new_msg, h, c, hc, cc) in [Na,Nb,..];
+        with ``noise`` ([Na,Nb,nA] ~ Exp(1)) also (actions int64, log-probs)."""
         cfg = self.cfg
         assert cfg is not None
         na, nb = cfg.nb_agents, cfg.batch
@@ -310,10 +311,18 @@ class HipEngine:
             th.empty(na, nb, cfg.n_b, device=dev), th.empty(na, nb, cfg.n_b, device=dev),
             th.empty(na, nb, cfg.n_a, device=dev), th.empty(na, nb, cfg.n_a, device=dev),
         )
+        extra: Tuple[th.Tensor, ...] = ()
+        nz = act = lp = None
+        if noise is not None:
+            nz = _need(noise, th.float32, "noise")
+            act = th.empty(na, nb, dtype=th.int64, device=dev)
+            lp = th.empty(na, nb, device=dev)
+            extra = (act, lp)
         check(self.lib.marl_step_forward(
             C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(False).data_ptr(),
-            *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _stream(dev)))
-        return outs
+            *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _ptr(nz), _ptr(act),
+            _ptr(lp), _stream(dev)))
+        return outs + extra
 
     def debug_buffer(self, name: str, t: int, train: bool = True) -> th.Tensor:
         """View [R, ld] of a named per-step activation inside the episode workspace (tests)."""
@@ -326,23 +335,47 @@ class HipEngine:
 
     # -- standalone environment kernels ------------------------------------------------
     def patch_gather(self, img: th.Tensor, pos: th.Tensor, f: int) -> th.Tensor:
-        img = _need(img, th.float32, "img")
-        pos = _need(pos, th.int64, "pos")
-        na, nb, _ = pos.shape
-        _, c, h, w = img.shape
-        obs = th.empty(na, nb, c, f, f, device=img.device)
-        check(self.lib.marl_patch_gather(img.data_ptr(), pos.data_ptr(), obs.data_ptr(), na, nb, c,
-                                         h, w, f, _stream(img.device)))
-        return obs
+        return patch_gather(img, pos, f)
 
     def transition(self, pos: th.Tensor, actions: th.Tensor, table: Sequence[Sequence[int]],
                    sizes: Sequence[int], f: int) -> th.Tensor:
-        pos = _need(pos, th.int64, "pos")
-        actions = _need(actions, th.int64, "actions")
-        out = th.empty_like(pos)
-        flat = (C.c_int32 * (2 * len(table)))(*[v for mv in table for v in mv])
-        rows = pos.shape[0] * pos.shape[1]
-        check(self.lib.marl_transition(pos.data_ptr(), actions.data_ptr(), out.data_ptr(), flat,
-                                       len(table), rows, sizes[0], sizes[1], f,
+        return transition(pos, actions, table, sizes, f)
+
+
+# Environment kernels need no model: module-level wrappers (core/environment.py uses them)
+def patch_gather(img: th.Tensor, pos: th.Tensor, f: int) -> th.Tensor:
+    """marl_patch_gather: obs[a,b] = img[b, :, p0:p0+f, p1:p1+f] (environment.py:95-126)."""
+    lib = _lib.load()
+    img = _need(img, th.float32, "img")
+    pos = _need(pos, th.int64, "pos")
+    na, nb, _ = pos.shape
+    _, c, h, w = img.shape
+    obs = th.empty(na, nb, c, f, f, device=img.device)
+    check(lib.marl_patch_gather(img.data_ptr(), pos.data_ptr(), obs.data_ptr(), na, nb, c, h, w, f,
+                                _stream(img.device)))
+    return obs
+
+
+def transition(pos: th.Tensor, actions: th.Tensor, table: Sequence[Sequence[int]],
+               sizes: Sequence[int], f: int) -> th.Tensor:
+    """marl_transition: bounded move (environment.py:56-66,128-150)."""
+    lib = _lib.load()
+    pos = _need(pos, th.int64, "pos")
+    actions = _need(actions, th.int64, "actions")
+    out = th.empty_like(pos)
+    flat = (C.c_int32 * (2 * len(table)))(*[v for mv in table for v in mv])
+    rows = pos.shape[0] * pos.shape[1]
+    check(lib.marl_transition(pos.data_ptr(), actions.data_ptr(), out.data_ptr(), flat, len(table),
+                              rows, sizes[0], sizes[1], f, _stream(pos.device)))
+    return out
+
+
+def normalize_positions(pos: th.Tensor, sizes: Sequence[int]) -> th.Tensor:
+    """marl_normalize_positions: pos / size per dimension (environment.py:74-81)."""
+    lib = _lib.load()
+    pos = _need(pos, th.int64, "pos")
+    out = th.empty(pos.shape, dtype=th.float32, device=pos.device)
+    rows = pos.shape[0] * pos.shape[1]
+    check(lib.marl_normalize_positions(pos.data_ptr(), out.data_ptr(), rows, sizes[0], sizes[1],
                                        _stream(pos.device)))
-        return out
+    return out

@@ -1,0 +1,47 @@
+"""Windowed meters (reference metrics.py) kept ON THE DEVICE: ``add`` enqueues a tiny
+bincount and never synchronises; the host only reads values when asked (``precision()``,
+``recall()``, ``loss()``), i.e. every ``log_interval`` iterations instead of 4-5 ``.item()``
+syncs per iteration (reference training/trainer.py:119-135).  Reporting code, not on the
+timed path."""
+
+from collections import deque
+from typing import Deque, Optional
+
+import torch as th
+
+
+class ConfusionMeter:
+    def __init__(self, nb_class: int, window_size: Optional[int] = None) -> None:
+        self.__nb_class = nb_class
+        self.__window: Deque[th.Tensor] = deque(maxlen=window_size)
+
+    def add(self, y_proba: th.Tensor, y_true: th.Tensor) -> None:
+        y_pred = y_proba.argmax(dim=1)
+        idx = y_true.to(y_pred.device) * self.__nb_class + y_pred
+        self.__window.append(th.bincount(idx, minlength=self.__nb_class**2))
+
+    def conf_mat(self) -> th.Tensor:
+        if not self.__window:
+            return th.zeros(self.__nb_class, self.__nb_class, dtype=th.long)
+        return th.stack(tuple(self.__window)).sum(0).view(self.__nb_class, self.__nb_class)
+
+    def precision(self) -> th.Tensor:
+        cm = self.conf_mat().to(th.float)
+        return cm.diagonal() / (cm.sum(dim=0) + 1e-8)
+
+    def recall(self) -> th.Tensor:
+        cm = self.conf_mat().to(th.float)
+        return cm.diagonal() / (cm.sum(dim=1) + 1e-8)
+
+
+class LossMeter:
+    def __init__(self, window_size: Optional[int] = None) -> None:
+        self.__window: Deque[th.Tensor] = deque(maxlen=window_size)
+
+    def add(self, value: th.Tensor) -> None:
+        self.__window.append(value.detach().reshape(()))
+
+    def loss(self) -> float:
+        if not self.__window:
+            return 0.0
+        return th.stack(tuple(self.__window)).mean().item()

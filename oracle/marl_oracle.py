@@ -438,6 +438,11 @@ def discounted_returns(rewards: th.Tensor, gamma: float) -> th.Tensor:
     return ret.flip(dims=(0,)).cumsum(0).flip(dims=(0,)) / gamma**t_steps
 
 
+def advantages(step_preds: th.Tensor, step_values: th.Tensor, y: th.Tensor, gamma: float) -> th.Tensor:
+    """returns - values (training/trainer.py:89-92), before standardisation."""
+    return discounted_returns(classification_rewards(step_preds, y), gamma) - step_values
+
+
 def standardize(values: th.Tensor, eps: float = 1e-8) -> th.Tensor:
     """training/functions.py:54-55 (unbiased std over ALL elements)."""
     return (values - values.mean()) / (values.std() + eps)
@@ -457,15 +462,21 @@ def a2c_loss(
     step_values: th.Tensor,
     y: th.Tensor,
     gamma: float,
+    adv_stats: Optional[Tuple[float, float]] = None,
 ) -> LossOut:
-    """training/trainer.py:76-111 and the scalars of :119-122."""
+    """training/trainer.py:76-111 and the scalars of :119-122.  ``adv_stats`` = (mean, std)
+    overrides the statistics ``standardize`` would compute from this batch (used to check
+    the data-parallel "exact standardize" exchange against a big-batch run)."""
     ns, _, nb, _ = step_preds.shape
     predictions = step_preds.mean(dim=1).flatten(0, 1)
     targets = y.unsqueeze(0).repeat(ns, 1).flatten(0, 1)
     error = F.cross_entropy(predictions, targets, reduction="none").unflatten(0, (ns, 1, nb))
     rewards = classification_rewards(step_preds, y)
     returns = discounted_returns(rewards, gamma)
-    adv = standardize(returns - step_values)
+    if adv_stats is None:
+        adv = standardize(returns - step_values)
+    else:
+        adv = ((returns - step_values) - adv_stats[0]) / (adv_stats[1] + 1e-8)
     path = -step_log_probas * adv.detach()
     actor = path + error
     critic = F.smooth_l1_loss(step_values, returns.detach(), reduction="none")
@@ -507,13 +518,14 @@ def train_iteration(
     gamma: float,
     faithful_crop: bool = False,
     forced_actions: Optional[th.Tensor] = None,
+    adv_stats: Optional[Tuple[float, float]] = None,
 ) -> Tuple[EpisodeTrace, LossOut, Params]:
     """One iteration of Trainer.train_epoch's body (training/trainer.py:73-114)
     up to and including ``loss.backward()``: returns the trace, the loss
     scalars and every parameter gradient (autograd on this restatement)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     tr = run_episode(leaves, cfg, img, inp, ns, faithful_crop, forced_actions)
-    lo = a2c_loss(tr.step_preds, tr.step_log_probas, tr.step_values, y, gamma)
+    lo = a2c_loss(tr.step_preds, tr.step_log_probas, tr.step_values, y, gamma, adv_stats)
     lo.loss.backward()
     grads = {
         k: (v.grad if v.grad is not None else th.zeros_like(v)) for k, v in leaves.items()
