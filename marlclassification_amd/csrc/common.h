@@ -187,6 +187,65 @@ int launch_softmax_rows(const float* logits, int ld, float* probs, int64_t rows,
                         hipStream_t st);
 
 // ---------------------------------------------------------------------------
+// row-panel MLP kernels (panel.hip)
+// ---------------------------------------------------------------------------
+struct PanelLayer {
+    const float* w;  // [n, ldw] packed, K-contiguous
+    int ldw;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    int n;
+    float* z;  // pre-LayerNorm output [M, ldz] (null when nothing is kept for backward)
+    int ldz;
+    float* stats;  // [M, 2] mean, rstd (nullable)
+    float* a;      // SiLU(LN(z)) [M, lda]
+    int lda;
+};
+struct PanelFwdProb {
+    const float* x;  // [M, ldx] input rows, or the message tensor when agg_na > 0
+    int ldx, k0;
+    int agg_na, agg_nb;  // message mean over the other agents computed while staging
+    float* xbar;         // [M, ldx] receives the staged input in agg mode (nullable)
+    int m, nlayers;
+    PanelLayer layer[2];
+};
+struct PanelFwdBatch {
+    PanelFwdProb p[2];
+    int count;
+    int off_panel1, off_red, off_part, off_prm;  // LDS float offsets (filled by the launcher)
+};
+int panel_supported(int k0, int n0, int n1);
+int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st);
+
+// backward of the same chain, layers listed from the LAST (output side) to the FIRST
+struct PanelBwdLayer {
+    const float* z;  // saved pre-LayerNorm activations [M, ldz]
+    int ldz;
+    const float* stats;  // [M, 2]
+    const float* gamma;
+    const float* beta;
+    int n;      // width of this layer's output
+    float* dz;  // out: d loss / d z [M, lddz] (kept for the weight gradients)
+    int lddz;
+    float* part;      // out: [gridDim.x][2][n] partial dgamma | dbeta of this launch
+    const float* wt;  // transposed weights [k_in, ldwt] (ldwt >= pad4(n)): dX = dz * W
+    int ldwt;
+    int k_in;  // width of this layer's input
+};
+struct PanelBwdProb {
+    const float* da;  // d loss / d (SiLU output of layer[0]) [M, ldda]
+    int ldda;
+    int m, nlayers;
+    PanelBwdLayer layer[2];
+    float* dx;  // out: d loss / d (input of the first layer) [M, lddx]
+    int lddx, accumulate;
+    int off_e, off_prm, off_colp, off_part;  // LDS float offsets (filled by the launcher)
+};
+int panel_bwd_blocks(int m);
+int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------
 // CNN data movement (cnn.hip)
 // ---------------------------------------------------------------------------
 // Patch gather fused with the first layer's im2col: img [Nb,Cimg,H,W], pos int32 [R,2]

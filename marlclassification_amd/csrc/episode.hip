@@ -16,6 +16,7 @@
 //     decode/encode), then every weight gradient as ONE row-contraction GEMM over all
 //     Ns*R rows, the full dU, and the CNN backward batched over all steps.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -237,7 +238,7 @@ struct ELayout {
     size_t ZC1, STC1, AC1, ZQ1, STQ1, AQ1;
     // backward only
     size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DAD1, DMBAR, DZE2, DAE1, DU,
-        DZPOS, BTMP;
+        DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
     size_t PART, CSUM, TNS, LOSS;
     size_t part_floats, csum_floats, tns_bytes, loss_floats;
@@ -314,6 +315,13 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         e.DZPOS = b.take(NR * d.ld_nd);
         int maxg = 4 * (d.n_b > d.n_a ? d.n_b : d.n_a);
         e.BTMP = b.take((size_t)maxg);
+        {   // per-step LayerNorm affine partials of the panel backward kernels
+            const size_t nblk = (size_t)panel_bwd_blocks((int)d.R) * d.ns * 2;
+            e.PLN[0] = b.take(nblk * d.n_mo);  // decode LN1
+            e.PLN[1] = b.take(nblk * d.nm2);   // decode LN0
+            e.PLN[2] = b.take(nblk * d.n_m);   // encode LN1
+            e.PLN[3] = b.take(nblk * d.nm2);   // encode LN0
+        }
         for (int l = 0; l < d.L; ++l) {
             e.DZ[l] = b.take(NR * d.P[l] * d.ch[l + 1]);
             e.DCOLS[l] = l > 0 ? b.take(NR * d.P[l] * d.ldk[l]) : 0;
@@ -444,11 +452,22 @@ struct StepIn {
     const float* img = nullptr;
 };
 
-static int step_core(const Ctx& c, int t, const StepIn& in) {
+static bool use_panels(const Dims& d) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("MARL_PANELS");
+        enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    return enabled && panel_supported(d.n_m, d.nm2, d.n_mo) && panel_supported(d.n_b, d.nm2, d.n_m) &&
+           panel_supported(d.n_a, d.nla, 0);
+}
+
+// ---- the five phases of one step; each only depends on what the comment names -----------
+
+// observation -> CNN features b_t -> U[t][:, :nf]            (needs POS[t])
+static int step_cnn(const Ctx& c, int t, const StepIn& in) {
     const Dims& d = c.d;
-    const int R = (int)d.R;
     hipStream_t st = c.st;
-    // --- observation -> CNN features b_t (networks/vision.py:23-52)
     if (in.obs)
         MARL_TRY(launch_obs_im2col(in.obs, c.at(c.e.COLS[0], t), d.ldk[0], d.R, d.c_img, d.ch[0],
                                    d.f, st));
@@ -472,7 +491,37 @@ static int step_core(const Ctx& c, int t, const StepIn& in) {
                                         d.P[l], co, d.grp[l], st));
         }
     }
-    // --- messages: mean over the other agents, decode (networks/models.py:97-98)
+    return MARL_OK;
+}
+
+// message mean over the other agents + decoder -> U[t][:, nf:nf+n_mo]   (needs MSG[t])
+static int step_decode(const Ctx& c, int t) {
+    const Dims& d = c.d;
+    const int R = (int)d.R;
+    hipStream_t st = c.st;
+    const bool keep = c.train != 0;
+    if (use_panels(d)) {
+        PanelFwdBatch pb{};
+        pb.count = 1;
+        PanelFwdProb& p = pb.p[0];
+        p.x = c.MSGs(t);
+        p.ldx = d.ld_nm;
+        p.k0 = d.n_m;
+        p.agg_na = d.na;
+        p.agg_nb = d.nb;
+        p.xbar = c.at(c.e.MBAR, t);
+        p.m = R;
+        p.nlayers = 2;
+        p.layer[0] = PanelLayer{c.wp(MARL_P_DEC_W0), p4(d.n_m), c.wp(MARL_P_DEC_B0),
+                                c.wp(MARL_P_DEC_LN0W), c.wp(MARL_P_DEC_LN0B), d.nm2,
+                                keep ? c.at(c.e.ZD1, t) : nullptr, d.ld_nm2,
+                                keep ? c.at(c.e.STD1, t) : nullptr, c.at(c.e.AD1, t), d.ld_nm2};
+        p.layer[1] = PanelLayer{c.wp(MARL_P_DEC_W1), d.ld_nm2, c.wp(MARL_P_DEC_B1),
+                                c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo,
+                                keep ? c.at(c.e.ZD2, t) : nullptr, d.ld_nmo,
+                                keep ? c.at(c.e.STD2, t) : nullptr, c.at(c.e.U, t) + d.nf, d.ld_nin};
+        return launch_panel_fwd(pb, st);
+    }
     MARL_TRY(launch_agg_msg(c.MSGs(t), c.at(c.e.MBAR, t), d.ld_nm, d.na, d.nb, d.n_m, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.MBAR, t), d.ld_nm, c.wp(MARL_P_DEC_W0), p4(d.n_m), d.n_m,
                                 c.at(c.e.ZD1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_DEC_B0))));
@@ -481,58 +530,163 @@ static int step_core(const Ctx& c, int t, const StepIn& in) {
                                 c.at(c.e.STD1, t), d.R, d.nm2, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AD1, t), d.ld_nm2, c.wp(MARL_P_DEC_W1), d.ld_nm2, d.nm2,
                                 c.at(c.e.ZD2, t), d.ld_nmo, R, d.n_mo, c.wp(MARL_P_DEC_B1))));
-    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZD2, t), d.ld_nmo, c.wp(MARL_P_DEC_LN1W),
-                                c.wp(MARL_P_DEC_LN1B), c.at(c.e.U, t) + d.nf, d.ld_nin,
-                                c.at(c.e.STD2, t), d.R, d.n_mo, st));
-    // --- position embedding (networks/models.py:101)
+    return launch_ln_silu_fwd(c.at(c.e.ZD2, t), d.ld_nmo, c.wp(MARL_P_DEC_LN1W),
+                              c.wp(MARL_P_DEC_LN1B), c.at(c.e.U, t) + d.nf, d.ld_nin,
+                              c.at(c.e.STD2, t), d.R, d.n_mo, st);
+}
+
+// position embedding + both LSTM cells -> H/C/H^/C^[t+1]     (needs all of U[t])
+static int step_pos_lstm(const Ctx& c, int t, const StepIn& in) {
+    const Dims& d = c.d;
+    const int R = (int)d.R;
+    hipStream_t st = c.st;
     MARL_TRY(launch_pos_embed_fwd(c.POSs(t), in.npos, d.H, d.W, c.wp(MARL_P_POS_W),
                                   c.wp(MARL_P_POS_B), c.wp(MARL_P_POS_LNW), c.wp(MARL_P_POS_LNB),
                                   c.at(c.e.NPOS, t), c.at(c.e.ZPOS, t), d.ld_nd, c.at(c.e.STPOS, t),
                                   c.at(c.e.U, t) + d.nf + d.n_mo, d.ld_nin, d.R, d.n_d, st));
-    // --- belief + action LSTM cells (networks/models.py:107-123), one grouped launch
-    {
-        GemmBatch b{};
-        b.count = 2;
-        GemmProb& pb = b.p[0];
-        pb = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LB_WIH), d.ld_nin, d.nin, nullptr, 0, R,
-                       d.n_b, c.W + c.w.bsum_b);
-        gemm_add_seg(pb, c.Hs(t), d.ld_nb, c.wp(MARL_P_LB_WHH), d.ld_nb, d.n_b);
-        pb.c_prev = c.Cs(t);
-        pb.h_next = c.Hs(t + 1);
-        pb.c_next = c.Cs(t + 1);
-        pb.gates = c.train ? c.at(c.e.GB, t) : nullptr;
-        pb.ld_state = d.ld_nb;
-        pb.ld_gates = d.ld_gb;
-        GemmProb& pa = b.p[1];
-        pa = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LA_WIH), d.ld_nin, d.nin, nullptr, 0, R,
-                       d.n_a, c.W + c.w.bsum_a);
-        gemm_add_seg(pa, c.HCs(t), d.ld_na, c.wp(MARL_P_LA_WHH), d.ld_na, d.n_a);
-        pa.c_prev = c.CCs(t);
-        pa.h_next = c.HCs(t + 1);
-        pa.c_next = c.CCs(t + 1);
-        pa.gates = c.train ? c.at(c.e.GA, t) : nullptr;
-        pa.ld_state = d.ld_na;
-        pa.ld_gates = d.ld_ga;
-        MARL_TRY(launch_gemm_lstm(b, st));
+    GemmBatch b{};
+    b.count = 2;
+    GemmProb& pb = b.p[0];
+    pb = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LB_WIH), d.ld_nin, d.nin, nullptr, 0, R,
+                   d.n_b, c.W + c.w.bsum_b);
+    gemm_add_seg(pb, c.Hs(t), d.ld_nb, c.wp(MARL_P_LB_WHH), d.ld_nb, d.n_b);
+    pb.c_prev = c.Cs(t);
+    pb.h_next = c.Hs(t + 1);
+    pb.c_next = c.Cs(t + 1);
+    pb.gates = c.train ? c.at(c.e.GB, t) : nullptr;
+    pb.ld_state = d.ld_nb;
+    pb.ld_gates = d.ld_gb;
+    GemmProb& pa = b.p[1];
+    pa = gemm_prob(c.at(c.e.U, t), d.ld_nin, c.wp(MARL_P_LA_WIH), d.ld_nin, d.nin, nullptr, 0, R,
+                   d.n_a, c.W + c.w.bsum_a);
+    gemm_add_seg(pa, c.HCs(t), d.ld_na, c.wp(MARL_P_LA_WHH), d.ld_na, d.n_a);
+    pa.c_prev = c.CCs(t);
+    pa.h_next = c.HCs(t + 1);
+    pa.c_next = c.CCs(t + 1);
+    pa.gates = c.train ? c.at(c.e.GA, t) : nullptr;
+    pa.ld_state = d.ld_na;
+    pa.ld_gates = d.ld_ga;
+    return launch_gemm_lstm(b, st);
+}
+
+static void fill_enc_prob(const Ctx& c, int t, PanelFwdProb& pe) {
+    const Dims& d = c.d;
+    const bool keep = c.train != 0;
+    pe.x = c.Hs(t + 1);
+    pe.ldx = d.ld_nb;
+    pe.k0 = d.n_b;
+    pe.m = (int)d.R;
+    pe.nlayers = 2;
+    pe.layer[0] = PanelLayer{c.wp(MARL_P_ENC_W0), d.ld_nb, c.wp(MARL_P_ENC_B0),
+                             c.wp(MARL_P_ENC_LN0W), c.wp(MARL_P_ENC_LN0B), d.nm2,
+                             keep ? c.at(c.e.ZE1, t) : nullptr, d.ld_nm2,
+                             keep ? c.at(c.e.STE1, t) : nullptr, c.at(c.e.AE1, t), d.ld_nm2};
+    pe.layer[1] = PanelLayer{c.wp(MARL_P_ENC_W1), d.ld_nm2, c.wp(MARL_P_ENC_B1),
+                             c.wp(MARL_P_ENC_LN1W), c.wp(MARL_P_ENC_LN1B), d.n_m,
+                             keep ? c.at(c.e.ZE2, t) : nullptr, d.ld_nm,
+                             keep ? c.at(c.e.STE2, t) : nullptr, c.MSGs(t + 1), d.ld_nm};
+}
+static void fill_pol_prob(const Ctx& c, int t, PanelFwdProb& pp) {
+    const Dims& d = c.d;
+    const bool keep = c.train != 0;
+    pp.x = c.HCs(t + 1);
+    pp.ldx = d.ld_na;
+    pp.k0 = d.n_a;
+    pp.m = (int)d.R;
+    pp.nlayers = 1;
+    pp.layer[0] = PanelLayer{c.wp(MARL_P_POL_W0), d.ld_na, c.wp(MARL_P_POL_B0),
+                             c.wp(MARL_P_POL_LNW), c.wp(MARL_P_POL_LNB), d.nla,
+                             keep ? c.at(c.e.ZP1, t) : nullptr, d.ld_nla,
+                             keep ? c.at(c.e.STP1, t) : nullptr, c.at(c.e.AP1, t), d.ld_nla};
+}
+
+// message encoder -> MSG[t+1] (which = 1), policy hidden layer -> AP1[t] (which = 2), or both
+// in one launch (which = 3).                                   (needs H / H^[t+1])
+static int step_encode_policy(const Ctx& c, int t, int which) {
+    const Dims& d = c.d;
+    const int R = (int)d.R;
+    hipStream_t st = c.st;
+    if (use_panels(d)) {
+        PanelFwdBatch pb{};
+        pb.count = 0;
+        if (which & 1) fill_enc_prob(c, t, pb.p[pb.count++]);
+        if (which & 2) fill_pol_prob(c, t, pb.p[pb.count++]);
+        return launch_panel_fwd(pb, st);
     }
-    // --- message encoder and policy hidden layer (networks/models.py:114-128)
-    MARL_TRY(gemm2(c,
-                   gemm_prob(c.Hs(t + 1), d.ld_nb, c.wp(MARL_P_ENC_W0), d.ld_nb, d.n_b,
-                             c.at(c.e.ZE1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_ENC_B0)),
-                   gemm_prob(c.HCs(t + 1), d.ld_na, c.wp(MARL_P_POL_W0), d.ld_na, d.n_a,
-                             c.at(c.e.ZP1, t), d.ld_nla, R, d.nla, c.wp(MARL_P_POL_B0))));
-    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE1, t), d.ld_nm2, c.wp(MARL_P_ENC_LN0W),
-                                c.wp(MARL_P_ENC_LN0B), c.at(c.e.AE1, t), d.ld_nm2,
-                                c.at(c.e.STE1, t), d.R, d.nm2, st));
-    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZP1, t), d.ld_nla, c.wp(MARL_P_POL_LNW),
-                                c.wp(MARL_P_POL_LNB), c.at(c.e.AP1, t), d.ld_nla,
-                                c.at(c.e.STP1, t), d.R, d.nla, st));
-    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AE1, t), d.ld_nm2, c.wp(MARL_P_ENC_W1), d.ld_nm2, d.nm2,
-                                c.at(c.e.ZE2, t), d.ld_nm, R, d.n_m, c.wp(MARL_P_ENC_B1))));
-    MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE2, t), d.ld_nm, c.wp(MARL_P_ENC_LN1W),
-                                c.wp(MARL_P_ENC_LN1B), c.MSGs(t + 1), d.ld_nm, c.at(c.e.STE2, t),
-                                d.R, d.n_m, st));
+    if (which == 3) {
+        MARL_TRY(gemm2(c,
+                       gemm_prob(c.Hs(t + 1), d.ld_nb, c.wp(MARL_P_ENC_W0), d.ld_nb, d.n_b,
+                                 c.at(c.e.ZE1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_ENC_B0)),
+                       gemm_prob(c.HCs(t + 1), d.ld_na, c.wp(MARL_P_POL_W0), d.ld_na, d.n_a,
+                                 c.at(c.e.ZP1, t), d.ld_nla, R, d.nla, c.wp(MARL_P_POL_B0))));
+    } else if (which == 1) {
+        MARL_TRY(gemm1(c, gemm_prob(c.Hs(t + 1), d.ld_nb, c.wp(MARL_P_ENC_W0), d.ld_nb, d.n_b,
+                                    c.at(c.e.ZE1, t), d.ld_nm2, R, d.nm2, c.wp(MARL_P_ENC_B0))));
+    } else {
+        MARL_TRY(gemm1(c, gemm_prob(c.HCs(t + 1), d.ld_na, c.wp(MARL_P_POL_W0), d.ld_na, d.n_a,
+                                    c.at(c.e.ZP1, t), d.ld_nla, R, d.nla, c.wp(MARL_P_POL_B0))));
+    }
+    if (which & 2)
+        MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZP1, t), d.ld_nla, c.wp(MARL_P_POL_LNW),
+                                    c.wp(MARL_P_POL_LNB), c.at(c.e.AP1, t), d.ld_nla,
+                                    c.at(c.e.STP1, t), d.R, d.nla, st));
+    if (which & 1) {
+        MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE1, t), d.ld_nm2, c.wp(MARL_P_ENC_LN0W),
+                                    c.wp(MARL_P_ENC_LN0B), c.at(c.e.AE1, t), d.ld_nm2,
+                                    c.at(c.e.STE1, t), d.R, d.nm2, st));
+        MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AE1, t), d.ld_nm2, c.wp(MARL_P_ENC_W1), d.ld_nm2,
+                                    d.nm2, c.at(c.e.ZE2, t), d.ld_nm, R, d.n_m,
+                                    c.wp(MARL_P_ENC_B1))));
+        MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZE2, t), d.ld_nm, c.wp(MARL_P_ENC_LN1W),
+                                    c.wp(MARL_P_ENC_LN1B), c.MSGs(t + 1), d.ld_nm,
+                                    c.at(c.e.STE2, t), d.R, d.n_m, st));
+    }
     return MARL_OK;
+}
+
+// whole step on one stream (standalone step API)
+static int step_core(const Ctx& c, int t, const StepIn& in) {
+    MARL_TRY(step_cnn(c, t, in));
+    MARL_TRY(step_decode(c, t));
+    MARL_TRY(step_pos_lstm(c, t, in));
+    return step_encode_policy(c, t, 3);
+}
+
+// ---------------------------------------------------------------------------
+// side stream: chains that are independent within a step run concurrently
+//   forward : message encoder(t) -> decoder(t+1)   ||  policy(t) -> sample(t) -> CNN(t+1)
+//   backward: W_hh recurrent GEMM(t)               ||  decoder / encoder backward chain(t)
+// ---------------------------------------------------------------------------
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[64];
+    int next = 0;
+    int init() {
+        if (s) return MARL_OK;
+        MARL_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (auto& e : ev) MARL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return MARL_OK;
+    }
+    // everything enqueued on `from` so far happens before what is enqueued on `to` afterwards
+    int order(hipStream_t from, hipStream_t to) {
+        hipEvent_t e = ev[next];
+        next = (next + 1) % 64;
+        MARL_HIP_CHECK(hipEventRecord(e, from));
+        MARL_HIP_CHECK(hipStreamWaitEvent(to, e, 0));
+        return MARL_OK;
+    }
+};
+static SideStream g_side;
+
+static bool use_side_stream() {
+    static int enabled = -1;
+    if (enabled < 0) {
+        // measured on MI355X (C3): no gain (16.38 vs 16.28 ms / iteration) - the cross-stream
+        // event waits cost what the overlap buys - so it is opt-in
+        const char* e = getenv("MARL_STREAMS");
+        enabled = (e && e[0] == '1') ? 1 : 0;
+    }
+    return enabled != 0;
 }
 
 // critic + prediction heads on `rows` rows starting at state slice t0 (+1)
@@ -769,6 +923,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     // ---- reverse-time loop over the recurrent chain ----------------------------------
     const size_t s_nmo = (size_t)d.R * d.ld_nmo, s_nm2 = (size_t)d.R * d.ld_nm2,
                  s_nm = (size_t)d.R * d.ld_nm;
+    const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
         MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
@@ -776,6 +931,16 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         MARL_TRY(launch_lstm_cell_bwd(c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
                                       c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1), d.ld_na, d.R,
                                       d.n_a, st));
+        // The W_hh recurrent GEMM (main stream) and the decoder / encoder backward chain (side
+        // stream) only meet at DH[t]: the chain's last kernel waits for the GEMM.
+        const bool side = panels && use_side_stream();
+        Ctx cs = c;
+        if (side) {
+            MARL_TRY(g_side.init());
+            cs.st = g_side.s;
+            MARL_TRY(g_side.order(c.st, cs.st));
+        }
+        hipStream_t st = cs.st;  // stream of the message chain below
         // recurrent paths: dh_{t-1} += dgates * W_hh
         MARL_TRY(gemm2(c,
                        gemm_prob(c.at(c.e.GB, t), d.ld_gb, c.wt(MARL_P_LB_WHH), d.ld_gb, 4 * d.n_b,
@@ -790,11 +955,58 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                                    ddbar, d.ld_nmo, R, d.n_mo);
             gemm_add_seg(p, c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga,
                          d.ld_ga, 4 * d.n_a);
-            MARL_TRY(gemm1(c, p));
+            MARL_TRY(gemm1(cs, p));
+        }
+        float* dad1 = c.at(c.e.DAD1) + (size_t)t * s_nm2;
+        if (panels) {
+            const size_t pblk = (size_t)panel_bwd_blocks(R) * 2;
+            PanelBwdProb pd{};
+            pd.da = ddbar;
+            pd.ldda = d.ld_nmo;
+            pd.m = R;
+            pd.nlayers = 2;
+            pd.layer[0] = PanelBwdLayer{c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
+                                        c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo, ddbar,
+                                        d.ld_nmo, c.at(c.e.PLN[0]) + (size_t)t * pblk * d.n_mo,
+                                        c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.nm2};
+            pd.layer[1] = PanelBwdLayer{c.at(c.e.ZD1, t), d.ld_nm2, c.at(c.e.STD1, t),
+                                        c.wp(MARL_P_DEC_LN0W), c.wp(MARL_P_DEC_LN0B), d.nm2, dad1,
+                                        d.ld_nm2, c.at(c.e.PLN[1]) + (size_t)t * pblk * d.nm2,
+                                        c.wt(MARL_P_DEC_W0), p4(d.nm2), d.n_m};
+            pd.dx = c.at(c.e.DMBAR);
+            pd.lddx = d.ld_nm;
+            pd.accumulate = 0;
+            MARL_TRY(launch_panel_bwd(pd, st));
+            if (t > 0) {
+                float* dze2 = c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm;
+                float* dae1 = c.at(c.e.DAE1) + (size_t)(t - 1) * s_nm2;
+                MARL_TRY(launch_agg_msg(c.at(c.e.DMBAR), dze2, d.ld_nm, d.na, d.nb, d.n_m, st));
+                PanelBwdProb pe{};
+                pe.da = dze2;
+                pe.ldda = d.ld_nm;
+                pe.m = R;
+                pe.nlayers = 2;
+                pe.layer[0] = PanelBwdLayer{c.at(c.e.ZE2, t - 1), d.ld_nm, c.at(c.e.STE2, t - 1),
+                                            c.wp(MARL_P_ENC_LN1W), c.wp(MARL_P_ENC_LN1B), d.n_m,
+                                            dze2, d.ld_nm,
+                                            c.at(c.e.PLN[2]) + (size_t)(t - 1) * pblk * d.n_m,
+                                            c.wt(MARL_P_ENC_W1), p4(d.n_m), d.nm2};
+                pe.layer[1] = PanelBwdLayer{c.at(c.e.ZE1, t - 1), d.ld_nm2, c.at(c.e.STE1, t - 1),
+                                            c.wp(MARL_P_ENC_LN0W), c.wp(MARL_P_ENC_LN0B), d.nm2,
+                                            dae1, d.ld_nm2,
+                                            c.at(c.e.PLN[3]) + (size_t)(t - 1) * pblk * d.nm2,
+                                            c.wt(MARL_P_ENC_W0), p4(d.nm2), d.n_b};
+                pe.dx = c.DHs(t);
+                pe.lddx = d.ld_nb;
+                pe.accumulate = 1;
+                if (side) MARL_TRY(g_side.order(c.st, cs.st));  // after the W_hh GEMM's DH[t] update
+                MARL_TRY(launch_panel_bwd(pe, st));
+            }
+            if (side) MARL_TRY(g_side.order(cs.st, c.st));  // join before step t-1
+            continue;
         }
         MARL_TRY(ln_bwd(c, ddbar, d.ld_nmo, c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
                         MARL_P_DEC_LN1W, MARL_P_DEC_LN1B, d.R, d.n_mo, grads, !first));
-        float* dad1 = c.at(c.e.DAD1) + (size_t)t * s_nm2;
         MARL_TRY(gemm1(c, gemm_prob(ddbar, d.ld_nmo, c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.n_mo, dad1,
                                     d.ld_nm2, R, d.nm2)));
         MARL_TRY(ln_bwd(c, dad1, d.ld_nm2, c.at(c.e.ZD1, t), d.ld_nm2, c.at(c.e.STD1, t),
@@ -816,6 +1028,19 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                             grads, !efirst));
             MARL_TRY(gemm1(c, gemm_prob(dae1, d.ld_nm2, c.wt(MARL_P_ENC_W0), p4(d.nm2), d.nm2,
                                         c.DHs(t), d.ld_nb, R, d.n_b, nullptr, 1)));
+        }
+    }
+    if (panels) {  // LayerNorm affine gradients of the in-loop layers: one reduction each
+        const int64_t nblk = panel_bwd_blocks(R);
+        MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[0]), nblk * ns, d.n_mo, grads[MARL_P_DEC_LN1W],
+                                      grads[MARL_P_DEC_LN1B], 0, st));
+        MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[1]), nblk * ns, d.nm2, grads[MARL_P_DEC_LN0W],
+                                      grads[MARL_P_DEC_LN0B], 0, st));
+        if (ns > 1) {
+            MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[2]), nblk * (ns - 1), d.n_m,
+                                          grads[MARL_P_ENC_LN1W], grads[MARL_P_ENC_LN1B], 0, st));
+            MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[3]), nblk * (ns - 1), d.nm2,
+                                          grads[MARL_P_ENC_LN0W], grads[MARL_P_ENC_LN0B], 0, st));
         }
     }
 
@@ -1002,8 +1227,27 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
     MARL_TRY(load_state(c, h0, c0, hc0, cc0, nullptr));
     StepIn in;
     in.img = img;
+    const bool side = use_side_stream();
+    Ctx c2 = c;
+    if (side) {
+        MARL_TRY(g_side.init());
+        c2.st = g_side.s;
+    }
     for (int t = 0; t < d.ns; ++t) {
-        MARL_TRY(step_core(c, t, in));
+        MARL_TRY(step_cnn(c, t, in));
+        if (!side || t == 0)
+            MARL_TRY(step_decode(c, t));
+        else
+            MARL_TRY(g_side.order(c2.st, c.st));  // decoder(t) ran on the side stream
+        MARL_TRY(step_pos_lstm(c, t, in));
+        if (side) {
+            MARL_TRY(g_side.order(c.st, c2.st));  // side stream: after the LSTM of step t
+            MARL_TRY(step_encode_policy(c2, t, 1));
+            if (t + 1 < d.ns) MARL_TRY(step_decode(c2, t + 1));
+            MARL_TRY(step_encode_policy(c, t, 2));
+        } else {
+            MARL_TRY(step_encode_policy(c, t, 3));
+        }
         SampleArgs a;
         fill_sample_args(c, cfg, t, a);
         a.noise = noise ? noise + (size_t)t * d.R * d.nA : nullptr;
@@ -1013,6 +1257,7 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         a.step_logp = step_logp + (size_t)t * d.R;
         MARL_TRY(launch_sample(a, c.st));
     }
+    if (side) MARL_TRY(g_side.order(c2.st, c.st));  // join before the caller's stream continues
     return heads_batched(c, 0, d.NR, step_values, step_preds);
 }
 

@@ -9,22 +9,25 @@
 // TM x TN accumulator tiles of 32x32 (16 VGPRs each).  Operand tiles are staged
 // global -> registers -> LDS (double buffered, one barrier per K tile); LDS rows are
 // padded to 20 floats so that the ds_read_b128 fragment reads are bank-conflict free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace marl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;          // K depth of one staged tile
-constexpr int LDS_K = BK + 4;   // padded LDS row stride (floats) for K-contiguous tiles
+constexpr int BK = 16;          // row depth of one staged tile of the TN kernel
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // accurate variants used where the result feeds saved state (error ~1 ulp)
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WM, int WN, bool LSTM>
+template <int BM, int BN, int WM, int WN, bool LSTM, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
+    constexpr int LDS_K = BK + 4;  // padded LDS row stride (floats): conflict-free b128 reads
+    constexpr int KC = BK / 4;     // float4 chunks per tile row
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_CH = BM * (BK / 4) / 256;
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
     static_assert(!LSTM || (WN == 1 && BN == 128), "LSTM tile = 4 gates x 32 units");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_K];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][(BM + BN) * LDS_K]
 
     const GemmProb& P = batch.p[blockIdx.z];
     const int M = P.m;
@@ -52,59 +55,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
     const int t1 = P.nseg > 1 ? (P.seg[1].k + BK - 1) / BK : 0;
     const int T = t0 + t1;
 
-    float4 ra[A_CH], rb[B_CH];
-
-    auto load_tile = [&](int tile) {
-        const bool s1 = tile >= t0;
-        const float* __restrict__ ga = s1 ? P.seg[1].a : P.seg[0].a;
-        const float* __restrict__ gb = s1 ? P.seg[1].b : P.seg[0].b;
-        const int lda = s1 ? P.seg[1].lda : P.seg[0].lda;
-        const int ldb = s1 ? P.seg[1].ldb : P.seg[0].ldb;
-        const int K4 = ((s1 ? P.seg[1].k : P.seg[0].k) + 3) & ~3;
-        const int k0 = (s1 ? tile - t0 : tile) * BK;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 2;
-            const int k = k0 + (c & 3) * 4;
-            int gm = m0 + row;
-            gm = gm < M ? gm : M - 1;
-            ra[i] = (k < K4) ? *reinterpret_cast<const float4*>(ga + (size_t)gm * lda + k)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 2;
-            const int k = k0 + (c & 3) * 4;
-            int gn;
-            if (LSTM) {
-                int unit = n0 + (row & 31);
-                unit = unit < N ? unit : N - 1;
-                gn = (row >> 5) * N + unit;
-            } else {
-                gn = n0 + row;
-                gn = gn < N ? gn : N - 1;
-            }
-            rb[i] = (k < K4) ? *reinterpret_cast<const float4*>(gb + (size_t)gn * ldb + k)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * (BM + BN) * LDS_K;
-        float* Bs = As + BM * LDS_K;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<float4*>(As + (c >> 2) * LDS_K + (c & 3) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<float4*>(Bs + (c >> 2) * LDS_K + (c & 3) * 4) = rb[i];
-        }
-    };
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -113,42 +63,131 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // Per-thread staging coordinates (fixed for the whole K loop): chunk c covers tile row
+    // c / KC, floats [(c % KC) * 4, +4).  Rows beyond M / N are clamped to the last valid row
+    // (their results are never stored).
+    const float* arow0[A_CH];
+    const float* arow1[A_CH];
+    const float* brow0[B_CH];
+    const float* brow1[B_CH];
+    int koff[A_CH > B_CH ? A_CH : B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + 256 * i;
+        int gm = m0 + c / KC;
+        gm = gm < M ? gm : M - 1;
+        arow0[i] = P.seg[0].a + (size_t)gm * P.seg[0].lda;
+        arow1[i] = P.nseg > 1 ? P.seg[1].a + (size_t)gm * P.seg[1].lda : arow0[i];
+        koff[i] = (c % KC) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / KC;
+        int gn;
+        if (LSTM) {
+            int unit = n0 + (row & 31);
+            unit = unit < N ? unit : N - 1;
+            gn = (row >> 5) * N + unit;
+        } else {
+            gn = n0 + row;
+            gn = gn < N ? gn : N - 1;
+        }
+        brow0[i] = P.seg[0].b + (size_t)gn * P.seg[0].ldb;
+        brow1[i] = P.nseg > 1 ? P.seg[1].b + (size_t)gn * P.seg[1].ldb : brow0[i];
+        koff[i] = (c % KC) * 4;  // same for A and B chunks (A_CH == B_CH or KC-periodic)
+    }
+    const int K4_0 = (P.seg[0].k + 3) & ~3;
+    const int K4_1 = P.nseg > 1 ? (P.seg[1].k + 3) & ~3 : 4;
+
+    // Loads are UNCONDITIONAL from clamped, always-valid addresses: a predicated load makes
+    // hipcc branch around it and drain vmcnt per load (one L2 round trip each).  K columns
+    // past the end are zeroed on the B side when the tile goes to LDS (weights are finite, so
+    // finite-garbage * 0 is exact).
+    // One register set: tile t+1 is requested right after the barrier of tile t and lands
+    // while tile t is computed.  (A second set / prefetch distance 2 was measured: no gain,
+    // the fp32 MFMA phase of ~3.5 us already covers the L2 latency.)
+    float4 raX0, raX1, raX2, raX3, rbX0, rbX1, rbX2, rbX3;
+    float mkX0 = 1.f, mkX1 = 1.f, mkX2 = 1.f, mkX3 = 1.f;
+#define MARL_LOAD_ONE(S, idx_, ia_, ib_)                                                   \
+    {                                                                                      \
+        const int k_ = k0_ + koff[ia_];                                                    \
+        const int kc_ = k_ < K4_ ? k_ : K4_ - 4;                                           \
+        ra##S##idx_ = *reinterpret_cast<const float4*>((s1_ ? arow1[ia_] : arow0[ia_]) + kc_); \
+        rb##S##idx_ = *reinterpret_cast<const float4*>((s1_ ? brow1[ib_] : brow0[ib_]) + kc_); \
+        mk##S##idx_ = k_ < K4_ ? 1.f : 0.f;                                                \
+    }
+#define MARL_LOAD_TILE(S, tile_)                                                           \
+    {                                                                                      \
+        const int s1_ = (tile_) >= t0 ? 1 : 0;                                             \
+        const int k0_ = (s1_ ? (tile_) - t0 : (tile_)) * BK;                               \
+        const int K4_ = s1_ ? K4_1 : K4_0;                                                 \
+        MARL_LOAD_ONE(S, 0, 0, 0)                                                          \
+        if (A_CH > 1) MARL_LOAD_ONE(S, 1, 1 % A_CH, 1 % B_CH)                              \
+        if (A_CH > 2) MARL_LOAD_ONE(S, 2, 2 % A_CH, 2 % B_CH)                              \
+        if (A_CH > 3) MARL_LOAD_ONE(S, 3, 3 % A_CH, 3 % B_CH)                              \
+    }
+#define MARL_STORE_ONE(S, idx_)                                                            \
+    if (A_CH > (idx_)) {                                                                   \
+        const int c_ = tid + 256 * (idx_);                                                 \
+        *reinterpret_cast<float4*>(As_ + (c_ / KC) * LDS_K + (c_ % KC) * 4) = ra##S##idx_; \
+        float4 v_ = rb##S##idx_;                                                           \
+        v_.x *= mk##S##idx_;                                                               \
+        v_.y *= mk##S##idx_;                                                               \
+        v_.z *= mk##S##idx_;                                                               \
+        v_.w *= mk##S##idx_;                                                               \
+        *reinterpret_cast<float4*>(Bs_ + (c_ / KC) * LDS_K + (c_ % KC) * 4) = v_;          \
+    }
+#define MARL_STORE_TILE(S, buf_)                                                           \
+    {                                                                                      \
+        float* As_ = smem + (buf_) * (BM + BN) * LDS_K;                                    \
+        float* Bs_ = As_ + BM * LDS_K;                                                     \
+        MARL_STORE_ONE(S, 0)                                                               \
+        MARL_STORE_ONE(S, 1)                                                               \
+        MARL_STORE_ONE(S, 2)                                                               \
+        MARL_STORE_ONE(S, 3)                                                               \
+    }
+#define MARL_COMPUTE_TILE(buf_)                                                            \
+    {                                                                                      \
+        const float* As = smem + (buf_) * (BM + BN) * LDS_K +                              \
+                          (wm * (BM / WM) + frag_row) * LDS_K + frag_k;                    \
+        const float* Bs = smem + (buf_) * (BM + BN) * LDS_K + BM * LDS_K +                 \
+                          (wn * (BN / WN) + frag_row) * LDS_K + frag_k;                    \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                            \
+            float4 a4[TM], b4[TN];                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
+                a4[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_K + kk * 8);    \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                 \
+                b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);    \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                           \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                          \
+        }                                                                                  \
+    }
+    static_assert(A_CH == B_CH && A_CH <= 4, "square tiles, at most 4 chunks per thread");
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
+    MARL_LOAD_TILE(X, 0)
     for (int tile = 0; tile < T; ++tile) {
+        // One barrier per tile: LDS buffer b was last read two tiles ago and every wave has
+        // passed the previous tile's barrier only after finishing those reads.
         const int buf = tile & 1;
-        if (tile + 1 < T) load_tile(tile + 1);
-
-        const float* As = smem + buf * (BM + BN) * LDS_K + (wm * (BM / WM) + frag_row) * LDS_K + frag_k;
-        const float* Bs = smem + buf * (BM + BN) * LDS_K + BM * LDS_K +
-                          (wn * (BN / WN) + frag_row) * LDS_K + frag_k;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 a4[TM], b4[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_K + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (tile + 1 < T) store_tile(buf ^ 1);
+        MARL_STORE_TILE(X, buf)
         __syncthreads();
+        if (tile + 1 < T) MARL_LOAD_TILE(X, tile + 1)
+        MARL_COMPUTE_TILE(buf)
     }
+#undef MARL_LOAD_ONE
+#undef MARL_STORE_TILE
+#undef MARL_COMPUTE_TILE
+#undef MARL_LOAD_TILE
+#undef MARL_STORE_ONE
 
     // ---- epilogue: acc[i][j][r] is C[row(r), col], col = lane & 31,
     //      row(r) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -233,45 +272,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int wm = wave / WN, wn = wave % WN;
     const int T = r_end > r_begin ? (int)((r_end - r_begin + BK - 1) / BK) : 0;
 
-    float4 ra[A_CH], rb[B_CH];
-    auto load_tile = [&](int tile) {
-        const int64_t rb0 = r_begin + (int64_t)tile * BK;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int kr = c / (BM / 4);
-            const int ic = (c % (BM / 4)) * 4;
-            const int64_t gr = rb0 + kr;
-            ra[i] = (gr < r_end && i0 + ic < NI4)
-                        ? *reinterpret_cast<const float4*>(A + (size_t)gr * lda + i0 + ic)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            const int kr = c / (BN / 4);
-            const int jc = (c % (BN / 4)) * 4;
-            const int64_t gr = rb0 + kr;
-            rb[i] = (gr < r_end && j0 + jc < NJ4)
-                        ? *reinterpret_cast<const float4*>(B + (size_t)gr * ldb + j0 + jc)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * BK * (BM + BN);
-        float* Bs = As + BK * BM;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<float4*>(As + (c / (BM / 4)) * BM + (c % (BM / 4)) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int c = tid + 256 * i;
-            *reinterpret_cast<float4*>(Bs + (c / (BN / 4)) * BN + (c % (BN / 4)) * 4) = rb[i];
-        }
-    };
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -280,16 +280,67 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (T > 0) {
-        load_tile(0);
-        store_tile(0);
+    // Staging coordinates of this thread's chunks: tile row kr, 4 columns at ic / jc (clamped
+    // into the padded width: columns past NI / NJ are never stored).  Loads are unconditional
+    // from clamped rows; rows past the split are zeroed on the A side at LDS-store time.
+    static_assert(A_CH == B_CH && A_CH <= 2, "square tiles");
+    int kr[A_CH];
+    const float* acol[A_CH];
+    const float* bcol[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = tid + 256 * i;
+        kr[i] = c / (BM / 4);
+        const int ic = i0 + (c % (BM / 4)) * 4;
+        const int jc = j0 + (c % (BN / 4)) * 4;
+        acol[i] = A + (ic < NI4 ? ic : NI4 - 4);
+        bcol[i] = B + (jc < NJ4 ? jc : NJ4 - 4);
     }
-    __syncthreads();
+    float4 ra0, ra1, rb0, rb1;
+    float mk0 = 1.f, mk1 = 1.f;
+#define MARL_TN_LOAD(tile_)                                                            \
+    {                                                                                  \
+        const int64_t base_ = r_begin + (int64_t)(tile_) * BK;                         \
+        {                                                                              \
+            const int64_t gr_ = base_ + kr[0];                                         \
+            const int64_t gc_ = gr_ < r_end ? gr_ : r_end - 1;                         \
+            ra0 = *reinterpret_cast<const float4*>(acol[0] + (size_t)gc_ * lda);       \
+            rb0 = *reinterpret_cast<const float4*>(bcol[0] + (size_t)gc_ * ldb);       \
+            mk0 = gr_ < r_end ? 1.f : 0.f;                                             \
+        }                                                                              \
+        if (A_CH > 1) {                                                                \
+            const int64_t gr_ = base_ + kr[1 % A_CH];                                  \
+            const int64_t gc_ = gr_ < r_end ? gr_ : r_end - 1;                         \
+            ra1 = *reinterpret_cast<const float4*>(acol[1 % A_CH] + (size_t)gc_ * lda); \
+            rb1 = *reinterpret_cast<const float4*>(bcol[1 % A_CH] + (size_t)gc_ * ldb); \
+            mk1 = gr_ < r_end ? 1.f : 0.f;                                             \
+        }                                                                              \
+    }
+#define MARL_TN_STORE(idx_, ra_, rb_, mk_)                                             \
+    if (A_CH > (idx_)) {                                                               \
+        const int c_ = tid + 256 * (idx_);                                             \
+        float4 v_ = ra_;                                                               \
+        v_.x *= mk_;                                                                   \
+        v_.y *= mk_;                                                                   \
+        v_.z *= mk_;                                                                   \
+        v_.w *= mk_;                                                                   \
+        *reinterpret_cast<float4*>(As_ + (c_ / (BM / 4)) * BM + (c_ % (BM / 4)) * 4) = v_; \
+        *reinterpret_cast<float4*>(Bs_ + (c_ / (BN / 4)) * BN + (c_ % (BN / 4)) * 4) = rb_; \
+    }
+
     const int fcol = lane & 31;
     const int fk = lane >> 5;
+    if (T > 0) MARL_TN_LOAD(0)
     for (int tile = 0; tile < T; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < T) load_tile(tile + 1);
+        {
+            float* As_ = smem + buf * BK * (BM + BN);
+            float* Bs_ = As_ + BK * BM;
+            MARL_TN_STORE(0, ra0, rb0, mk0)
+            MARL_TN_STORE(1, ra1, rb1, mk1)
+        }
+        __syncthreads();
+        if (tile + 1 < T) MARL_TN_LOAD(tile + 1)
         const float* As = smem + buf * BK * (BM + BN) + wm * (BM / WM) + fcol;
         const float* Bs = smem + buf * BK * (BM + BN) + BK * BM + wn * (BN / WN) + fcol;
 #pragma unroll
@@ -305,9 +356,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (tile + 1 < T) store_tile(buf ^ 1);
-        __syncthreads();
     }
+#undef MARL_TN_LOAD
+#undef MARL_TN_STORE
 
     float* o = out + (size_t)blockIdx.z * out_split_stride;
     const int row_h = 4 * (lane >> 5);
@@ -367,6 +418,31 @@ void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb,
 static void prof_before(int cls, hipStream_t st);
 static void prof_after(int cls, hipStream_t st);
 
+template <int BM, int BN, int WM, int WN, bool LSTM, int BKT>
+static int launch_nt_variant(dim3 grid, const GemmBatch& batch, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, BKT>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;  // opt in to > 64 KiB of dynamic LDS once per kernel
+        if (!raised) {
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, batch);
+    return MARL_OK;
+}
+
+static int gemm_bk() {
+    static int bk = 0;
+    if (!bk) {
+        const char* e = getenv("MARL_GEMM_BK");
+        bk = (e && atoi(e) == 16) ? 16 : 32;
+    }
+    return bk;
+}
+
 static int check_prob(const GemmProb& p) {
     for (int s = 0; s < p.nseg; ++s) {
         const GemmSeg& g = p.seg[s];
@@ -399,10 +475,16 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
     prof_before(1, st);
     if (blocks128 >= 256 && max_n >= 96) {
         dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, batch);
+        if (gemm_bk() == 32)
+            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 32>(grid, batch, st)));
+        else
+            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 16>(grid, batch, st)));
     } else {
         dim3 grid((unsigned)cdiv(max_m, 64), (unsigned)cdiv(max_n, 64), (unsigned)batch.count);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, batch);
+        if (gemm_bk() == 32)
+            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 32>(grid, batch, st)));
+        else
+            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 16>(grid, batch, st)));
     }
     prof_after(1, st);
     MARL_LAUNCH_CHECK();
@@ -469,7 +551,10 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
     }
     dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
     prof_before(0, st);
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 1, true>), grid, dim3(256), 0, st, batch);
+    if (gemm_bk() == 32)
+        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 32>(grid, batch, st)));
+    else
+        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 16>(grid, batch, st)));
     prof_after(0, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;

@@ -39,3 +39,21 @@ def main() -> None:
 
 if __name__ == "__main__":
     main()
+
+
+def gaps(path: str) -> None:
+    """busy time vs wall span of the trace's last third (steady state)"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select start, end from kernels order by start").fetchall()
+    rows = rows[len(rows) * 2 // 3:]
+    busy = sum(e - s for s, e in rows)
+    span = rows[-1][1] - rows[0][0]
+    gap = [rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1)]
+    big = sorted(gap)[-5:]
+    print(f"# last third: {len(rows)} kernels, busy {busy / 1e6:.3f} ms, span {span / 1e6:.3f} ms, "
+          f"idle {100 * (1 - busy / span):.1f} %, mean gap {sum(gap) / len(gap) / 1e3:.2f} us, "
+          f"largest gaps {[round(g / 1e3, 1) for g in big]} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1:
+    gaps(sys.argv[1])
