@@ -129,6 +129,11 @@ int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w,
 int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
                          const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
                          hipStream_t st);
+int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, float* gates0,
+                          int ldg0, const float* cp0, const float* cn0, int ldc0, int n0,
+                          const float* dh1, int lddh1, float* dc1, int lddc1, float* gates1,
+                          int ldg1, const float* cp1, const float* cn1, int ldc1, int n1,
+                          int64_t rows, hipStream_t st);
 
 struct SampleArgs {
     const float* a_pol;  // [R, ld_a] SiLU(LN(policy hidden))
@@ -147,6 +152,16 @@ struct SampleArgs {
     int32_t* actions_i32;          // [R] saved
     int R, nA, H, W, f;
     int32_t table[MARL_MAX_ACTIONS][2];
+    // optional: position embedding of the next step (written for step t+1)
+    const float* pe_W;  // packed [nd, 4]; null = off
+    const float* pe_b;
+    const float* pe_gamma;
+    const float* pe_beta;
+    float* pe_npos;   // [R, 4]
+    float* pe_z;      // [R, pe_ldz]
+    float* pe_stats;  // [R, 2]
+    float* pe_out;    // [R, pe_ldo] (the lambda slice of U[t+1])
+    int pe_ldz, pe_ldo, pe_nd;
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 

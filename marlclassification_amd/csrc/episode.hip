@@ -536,10 +536,11 @@ static int step_decode(const Ctx& c, int t) {
 }
 
 // position embedding + both LSTM cells -> H/C/H^/C^[t+1]     (needs all of U[t])
-static int step_pos_lstm(const Ctx& c, int t, const StepIn& in) {
+static int step_pos_lstm(const Ctx& c, int t, const StepIn& in, bool pos_done = false) {
     const Dims& d = c.d;
     const int R = (int)d.R;
     hipStream_t st = c.st;
+    if (!pos_done)
     MARL_TRY(launch_pos_embed_fwd(c.POSs(t), in.npos, d.H, d.W, c.wp(MARL_P_POS_W),
                                   c.wp(MARL_P_POS_B), c.wp(MARL_P_POS_LNW), c.wp(MARL_P_POS_LNB),
                                   c.at(c.e.NPOS, t), c.at(c.e.ZPOS, t), d.ld_nd, c.at(c.e.STPOS, t),
@@ -926,11 +927,11 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
-        MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
-                                      d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.R, d.n_b, st));
-        MARL_TRY(launch_lstm_cell_bwd(c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
-                                      c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1), d.ld_na, d.R,
-                                      d.n_a, st));
+        MARL_TRY(launch_lstm_cell_bwd2(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
+                                       d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.n_b,
+                                       c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
+                                       c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1), d.ld_na,
+                                       d.n_a, d.R, st));
         // The W_hh recurrent GEMM (main stream) and the decoder / encoder backward chain (side
         // stream) only meet at DH[t]: the chain's last kernel waits for the GEMM.
         const bool side = panels && use_side_stream();
@@ -941,21 +942,29 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             MARL_TRY(g_side.order(c.st, cs.st));
         }
         hipStream_t st = cs.st;  // stream of the message chain below
-        // recurrent paths: dh_{t-1} += dgates * W_hh
-        MARL_TRY(gemm2(c,
-                       gemm_prob(c.at(c.e.GB, t), d.ld_gb, c.wt(MARL_P_LB_WHH), d.ld_gb, 4 * d.n_b,
-                                 c.DHs(t), d.ld_nb, R, d.n_b, nullptr, 1),
-                       gemm_prob(c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WHH), d.ld_ga, 4 * d.n_a,
-                                 c.DHCs(t), d.ld_na, R, d.n_a, nullptr, 1)));
-        // d(decoded message) = columns [nf, nf + n_mo) of dU
+        // recurrent paths dh_{t-1} += dgates * W_hh, and d(decoded message) = columns
+        // [nf, nf + n_mo) of dU - three independent products of the same gate gradients
         float* ddbar = c.at(c.e.DDBAR) + (size_t)t * s_nmo;
         {
+            GemmBatch gb{};
+            gb.p[0] = gemm_prob(c.at(c.e.GB, t), d.ld_gb, c.wt(MARL_P_LB_WHH), d.ld_gb, 4 * d.n_b,
+                                c.DHs(t), d.ld_nb, R, d.n_b, nullptr, 1);
+            gb.p[1] = gemm_prob(c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WHH), d.ld_ga, 4 * d.n_a,
+                                c.DHCs(t), d.ld_na, R, d.n_a, nullptr, 1);
             GemmProb p = gemm_prob(c.at(c.e.GB, t), d.ld_gb,
                                    c.wt(MARL_P_LB_WIH) + (size_t)d.nf * d.ld_gb, d.ld_gb, 4 * d.n_b,
                                    ddbar, d.ld_nmo, R, d.n_mo);
             gemm_add_seg(p, c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga,
                          d.ld_ga, 4 * d.n_a);
-            MARL_TRY(gemm1(cs, p));
+            if (side) {  // W_hh products on the main stream, the message chain on the side stream
+                gb.count = 2;
+                MARL_TRY(launch_gemm_nt(gb, c.st));
+                MARL_TRY(gemm1(cs, p));
+            } else {
+                gb.p[2] = p;
+                gb.count = 3;
+                MARL_TRY(launch_gemm_nt(gb, c.st));
+            }
         }
         float* dad1 = c.at(c.e.DAD1) + (size_t)t * s_nm2;
         if (panels) {
@@ -1239,7 +1248,7 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
             MARL_TRY(step_decode(c, t));
         else
             MARL_TRY(g_side.order(c2.st, c.st));  // decoder(t) ran on the side stream
-        MARL_TRY(step_pos_lstm(c, t, in));
+        MARL_TRY(step_pos_lstm(c, t, in, t > 0));  // lambda_t (t > 0) came from sample(t-1)
         if (side) {
             MARL_TRY(g_side.order(c.st, c2.st));  // side stream: after the LSTM of step t
             MARL_TRY(step_encode_policy(c2, t, 1));
@@ -1255,6 +1264,19 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         a.step_pos = step_pos ? step_pos + (size_t)t * d.R * 2 : nullptr;
         a.step_actions = step_actions ? step_actions + (size_t)t * d.R : nullptr;
         a.step_logp = step_logp + (size_t)t * d.R;
+        if (t + 1 < d.ns) {  // position embedding of step t+1 rides along with the move
+            a.pe_W = c.wp(MARL_P_POS_W);
+            a.pe_b = c.wp(MARL_P_POS_B);
+            a.pe_gamma = c.wp(MARL_P_POS_LNW);
+            a.pe_beta = c.wp(MARL_P_POS_LNB);
+            a.pe_npos = c.at(c.e.NPOS, t + 1);
+            a.pe_z = c.at(c.e.ZPOS, t + 1);
+            a.pe_stats = c.at(c.e.STPOS, t + 1);
+            a.pe_out = c.at(c.e.U, t + 1) + d.nf + d.n_mo;
+            a.pe_ldz = d.ld_nd;
+            a.pe_ldo = d.ld_nin;
+            a.pe_nd = d.n_d;
+        }
         MARL_TRY(launch_sample(a, c.st));
     }
     if (side) MARL_TRY(g_side.order(c2.st, c.st));  // join before the caller's stream continues

@@ -506,33 +506,63 @@ int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w,
 // LSTM cell backward (pointwise part). gates holds activated i|f|g|o on entry and the
 // pre-activation gradients on exit; dc holds dL/dc_t on entry and dL/dc_{t-1} on exit.
 // ---------------------------------------------------------------------------
-__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, int lddh,
-                                     float* __restrict__ dc, int lddc, float* __restrict__ gates,
-                                     int ldg, const float* __restrict__ c_prev,
-                                     const float* __restrict__ c_new, int ldc, int64_t rows,
-                                     int n) {
+struct LstmBwdArgs {
+    const float* dh;
+    float* dc;
+    float* gates;
+    const float* c_prev;
+    const float* c_new;
+    int lddh, lddc, ldg, ldc, n;
+};
+struct LstmBwdBatch {
+    LstmBwdArgs a[2];
+    int64_t rows;
+};
+
+__global__ void lstm_cell_bwd_kernel(const LstmBwdBatch B) {
+    const LstmBwdArgs& A = B.a[blockIdx.y];
+    const int n = A.n;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * n) return;
+    if (idx >= B.rows * n) return;
     const int64_t r = idx / n;
     const int u = (int)(idx % n);
-    float* g = gates + r * ldg + u;
+    float* g = A.gates + r * A.ldg + u;
     const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
-    const float tc = tanhf(c_new[r * ldc + u]);
-    const float dhv = dh[r * lddh + u];
-    const float dcv = dhv * go * (1.0f - tc * tc) + dc[r * lddc + u];
+    const float tc = tanhf(A.c_new[r * A.ldc + u]);
+    const float dhv = A.dh[r * A.lddh + u];
+    const float dcv = dhv * go * (1.0f - tc * tc) + A.dc[r * A.lddc + u];
     g[0] = dcv * gg * gi * (1.0f - gi);
-    g[n] = dcv * c_prev[r * ldc + u] * gf * (1.0f - gf);
+    g[n] = dcv * A.c_prev[r * A.ldc + u] * gf * (1.0f - gf);
     g[2 * n] = dcv * gi * (1.0f - gg * gg);
     g[3 * n] = dhv * tc * go * (1.0f - go);
-    dc[r * lddc + u] = dcv * gf;
+    A.dc[r * A.lddc + u] = dcv * gf;
 }
 
 int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
                          const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
                          hipStream_t st) {
-    const int64_t tot = rows * n;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, dh,
-                       lddh, dc, lddc, gates, ldg, c_prev, c_new, ldc, rows, n);
+    LstmBwdBatch b{};
+    b.a[0] = LstmBwdArgs{dh, dc, gates, c_prev, c_new, lddh, lddc, ldg, ldc, n};
+    b.rows = rows;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(rows * n, 256), 1), dim3(256), 0, st,
+                       b);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// belief and action cells in one launch
+int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, float* gates0,
+                          int ldg0, const float* cp0, const float* cn0, int ldc0, int n0,
+                          const float* dh1, int lddh1, float* dc1, int lddc1, float* gates1,
+                          int ldg1, const float* cp1, const float* cn1, int ldc1, int n1,
+                          int64_t rows, hipStream_t st) {
+    LstmBwdBatch b{};
+    b.a[0] = LstmBwdArgs{dh0, dc0, gates0, cp0, cn0, lddh0, lddc0, ldg0, ldc0, n0};
+    b.a[1] = LstmBwdArgs{dh1, dc1, gates1, cp1, cn1, lddh1, lddc1, ldg1, ldc1, n1};
+    b.rows = rows;
+    const int nmax = n0 > n1 ? n0 : n1;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(rows * nmax, 256), 2), dim3(256), 0,
+                       st, b);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -608,6 +638,39 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
             A.step_pos[(size_t)r * 2 + 1] = n1;
         }
         if (A.step_actions) A.step_actions[r] = act;
+    }
+    // position embedding of the NEXT step (networks/state.py:14-16 on pos / size), so that no
+    // separate launch sits between the move and the next LSTM
+    if (A.pe_W) {
+        const int n0 = __shfl(lane == 0 ? A.pos_out[r * 2] : 0, 0);
+        const int n1 = __shfl(lane == 0 ? A.pos_out[r * 2 + 1] : 0, 0);
+        const float p0 = (float)n0 / (float)A.H, p1 = (float)n1 / (float)A.W;
+        const int nd = A.pe_nd;
+        if (lane == 0 && A.pe_npos) {
+            A.pe_npos[(size_t)r * 4] = p0;
+            A.pe_npos[(size_t)r * 4 + 1] = p1;
+        }
+        float s = 0.f;
+        for (int j = lane; j < nd; j += 64) {
+            const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
+            A.pe_z[(size_t)r * A.pe_ldz + j] = v;
+            s += v;
+        }
+        const float mean = wave_sum(s) / (float)nd;
+        float q = 0.f;
+        for (int j = lane; j < nd; j += 64) {
+            const float dd = (A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1]) - mean;
+            q += dd * dd;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)nd + 1e-5f);
+        if (lane == 0 && A.pe_stats) {
+            A.pe_stats[(size_t)r * 2] = mean;
+            A.pe_stats[(size_t)r * 2 + 1] = rstd;
+        }
+        for (int j = lane; j < nd; j += 64) {
+            const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
+            A.pe_out[(size_t)r * A.pe_ldo + j] = silu_f((v - mean) * rstd * A.pe_gamma[j] + A.pe_beta[j]);
+        }
     }
 }
 
