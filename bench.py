@@ -103,8 +103,10 @@ def main() -> None:
 
     import torch.distributed as dist
 
-    if world > 1:
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (any world size)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from marlclassification_amd import _lib
@@ -122,7 +124,7 @@ def main() -> None:
                         C3["n_d"], C3["nb_class"], C3["nlb"], C3["nla"])
     flat = FlatParams(param_shapes(ocfg), dev)
     flat.load(init_params(ocfg, 0))  # reference init recipe (networks/init.py), same on all ranks
-    hook = GradAllReduce(world) if world > 1 else None
+    hook = GradAllReduce(world) if distributed else None
     fa = FusedA2C(eng, flat, LR, GAMMA, allreduce=hook)
 
     gen = th.Generator(device=dev).manual_seed(shard_seed(0, rank))
@@ -138,7 +140,7 @@ def main() -> None:
             fa.iteration(img, y, draws)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         th.cuda.synchronize()
 
@@ -150,19 +152,22 @@ def main() -> None:
         one_step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = th.tensor([dt], dtype=th.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
     # ---- roofline of the dominant kernel (fused LSTM GEMM), HIP events on its stream ------
+    # Every rank runs the extra iterations (they contain the gradient all-reduce); only rank 0
+    # records events around its LSTM launches.
     roofline = None
     cpu = None
+    nprof = 3
     if rank == 0:
-        nprof = 3
         lib.marl_profile_begin(0, nprof * NS + 8)
-        for _ in range(nprof):
-            one_step()
+    for _ in range(nprof):
+        one_step()
+    if rank == 0:
         tot, cnt = C.c_double(0), C.c_int(0)
         lib.marl_profile_end(C.byref(tot), C.byref(cnt))
         avg_s = tot.value / max(1, cnt.value) / 1e3
@@ -173,7 +178,7 @@ def main() -> None:
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value, "traffic": None,
         }
-    if world > 1:
+    if distributed:
         dist.barrier()
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
         cpu = cpu_baseline()
@@ -197,7 +202,7 @@ def main() -> None:
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
