@@ -178,6 +178,13 @@ def main() -> None:
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value, "traffic": None,
         }
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE; profiles/r01_lstm_traffic.json says how they were taken)
+        tpath = os.path.join(ROOT, "profiles", "r01_lstm_traffic.json")
+        if nb == 256 and os.path.exists(tpath):
+            with open(tpath, "r", encoding="utf-8") as f:
+                roofline["traffic"] = json.load(f)["traffic_bytes_per_launch"]
+            roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_lstm_traffic.json)"
     if distributed:
         dist.barrier()
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
