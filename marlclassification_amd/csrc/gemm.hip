@@ -19,10 +19,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;          // row depth of one staged tile of the TN kernel
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-
-// accurate variants used where the result feeds saved state (error ~1 ulp)
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities of the fused LSTM epilogue: v_exp_f32 / v_rcp_f32 based (~1e-7
+// absolute error, well inside the 1e-5 parity budget; checked by the golden-vector tests).
+// The accurate libm forms cost ~10 us per launch in the epilogue of a 120 us kernel.
+__device__ __forceinline__ float sigmoid_acc(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    // 1 - 2 / (1 + e^{2x}); e^{2x} -> inf gives 1, -> 0 gives -1
+    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+}
 
 template <int BM, int BN, int WM, int WN, bool LSTM, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
@@ -223,12 +229,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
                 if (row < M) {
                     const float gi = sigmoid_acc(acc[0][0][r] + bi);
                     const float gf = sigmoid_acc(acc[0][1][r] + bf);
-                    const float gg = tanhf(acc[0][2][r] + bg);
+                    const float gg = tanh_fast(acc[0][2][r] + bg);
                     const float go = sigmoid_acc(acc[0][3][r] + bo);
                     const size_t so = (size_t)row * P.ld_state + unit;
                     const float cn = gf * P.c_prev[so] + gi * gg;
                     P.c_next[so] = cn;
-                    P.h_next[so] = go * tanhf(cn);
+                    P.h_next[so] = go * tanh_fast(cn);
                     if (P.gates) {
                         float* gp = P.gates + (size_t)row * P.ld_gates + unit;
                         gp[0] = gi;
