@@ -59,6 +59,9 @@ typedef struct marl_config {
     int32_t nb_action, nb_class;
     int32_t nlb, nla;    /* hidden_size_belief / hidden_size_action of the heads */
     int32_t actions[MARL_MAX_ACTIONS][2]; /* movement per action index (dim 0 = H) */
+    int32_t img_u8;      /* 1: the image batch is uint8 [Nb,C,H,W]; the gather kernel applies
+                            ToTensor (x / 255, registry.py:56-57) on the fly - 4x less HBM and
+                            PCIe traffic than uploading fp32 */
 } marl_config;
 
 /* Parameter table: an array of MARL_NPARAMS device pointers in this order.
@@ -111,14 +114,14 @@ int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_
                     int h, int w, int f, void* stream);
 
 /* EpisodeSampler.__episode_impl (core/episode.py:32-82) with the reference's random
- * draws as INPUTS: pos0 int64 [R,2]; h0,c0 [R,n_b]; hc0,cc0 [R,n_a];
+ * draws as INPUTS: img fp32 (or uint8 when cfg->img_u8) [Nb,C,H,W]; pos0 int64 [R,2]; h0,c0 [R,n_b]; hc0,cc0 [R,n_a];
  * noise [Ns,R,nA] ~ Exp(1) (th.multinomial == argmax(p / noise)).
  * forced_actions (int64 [Ns,R]) may be NULL; if given it replaces sampling.
  * Outputs: step_preds [Ns,R,nC], step_logp [Ns,R], step_values [Ns,R],
  * step_pos int64 [Ns,R,2] (after move t), step_actions int64 [Ns,R] (may be NULL).
  * With train != 0 the activations needed by marl_episode_backward stay in episode_ws. */
 int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
-                         const float* img, const int64_t* pos0,
+                         const void* img, const int64_t* pos0,
                          const float* h0, const float* c0, const float* hc0, const float* cc0,
                          const float* noise, const int64_t* forced_actions,
                          float* step_preds, float* step_logp, float* step_values,

@@ -43,6 +43,7 @@ class MarlConfig(C.Structure):
         ("nlb", C.c_int32),
         ("nla", C.c_int32),
         ("actions", (C.c_int32 * 2) * MARL_MAX_ACTIONS),
+        ("img_u8", C.c_int32),
     ]
 
 

@@ -82,7 +82,8 @@ class EpisodeSampler:
         img = img_batch.to(device)
         na, nb, ns = len(agents), img.shape[0], self.__nb_step
         eng = model.hip_engine(env.actions)
-        eng.configure(na, nb, ns, img.shape[1:])
+        # uint8 batches ([Nb,C,H,W], 0..255) stay uint8: ToTensor happens inside the gather kernel
+        eng.configure(na, nb, ns, img.shape[1:], img_u8=img.dtype == th.uint8)
         model.ensure_packed(eng)
         pos0 = env.place(img, na)
         if self.fixed_draws is not None:

@@ -12,9 +12,9 @@ namespace marl {
 // gather + im2col of layer 0.  A workgroup stages RB patches in LDS with coalesced row
 // segment reads (f contiguous floats per (channel, line)), then emits the im2col rows.
 // ---------------------------------------------------------------------------
-template <bool FROM_OBS>
+template <bool FROM_OBS, typename PIX>
 __global__ __launch_bounds__(256) void gather_im2col_kernel(
-    const float* __restrict__ img, const int32_t* __restrict__ pos, float* __restrict__ cols,
+    const PIX* __restrict__ img, const int32_t* __restrict__ pos, float* __restrict__ cols,
     int ldk, int64_t rows, int nb, int c_img, int cin, int H, int W, int f, int rb) {
     extern __shared__ __attribute__((aligned(16))) float patch[];  // [rb][cin][f][f]
     const int ff = f * f;
@@ -27,12 +27,13 @@ __global__ __launch_bounds__(256) void gather_im2col_kernel(
         const int64_t r = row0 + lr;
         float v;
         if (FROM_OBS) {
-            v = img[((r * c_img + ci) * f + y) * f + x];
+            v = (float)img[((r * c_img + ci) * f + y) * f + x];
         } else {
             const int b = (int)(r % nb);
             const int p0 = pos[r * 2], p1 = pos[r * 2 + 1];
-            v = img[(((int64_t)b * c_img + ci) * H + (p0 + y)) * W + (p1 + x)];
+            v = (float)img[(((int64_t)b * c_img + ci) * H + (p0 + y)) * W + (p1 + x)];
         }
+        if (sizeof(PIX) == 1) v = v / 255.0f;  // ToTensor on the fly (uint8 images)
         patch[idx] = v;
     }
     __syncthreads();
@@ -61,8 +62,8 @@ static int gather_rb(int cin, int f) {
     return rb;
 }
 
-int launch_gather_im2col(const float* img, const int32_t* pos, float* cols, int ldk, int na,
-                         int nb, int c_img, int cin, int H, int W, int f, hipStream_t st) {
+int launch_gather_im2col(const void* img, int img_u8, const int32_t* pos, float* cols, int ldk,
+                         int na, int nb, int c_img, int cin, int H, int W, int f, hipStream_t st) {
     const int64_t rows = (int64_t)na * nb;
     const int rb = gather_rb(cin, f);
     const size_t lds = (size_t)rb * cin * f * f * sizeof(float);
@@ -70,8 +71,15 @@ int launch_gather_im2col(const float* img, const int32_t* pos, float* cols, int 
         set_error("window %d too large for the gather kernel", f);
         return MARL_ELIMIT;
     }
-    hipLaunchKernelGGL((gather_im2col_kernel<false>), dim3((unsigned)cdiv(rows, rb)), dim3(256),
-                       lds, st, img, pos, cols, ldk, rows, nb, c_img, cin, H, W, f, rb);
+    if (img_u8)
+        hipLaunchKernelGGL((gather_im2col_kernel<false, unsigned char>),
+                           dim3((unsigned)cdiv(rows, rb)), dim3(256), lds, st,
+                           static_cast<const unsigned char*>(img), pos, cols, ldk, rows, nb, c_img,
+                           cin, H, W, f, rb);
+    else
+        hipLaunchKernelGGL((gather_im2col_kernel<false, float>), dim3((unsigned)cdiv(rows, rb)),
+                           dim3(256), lds, st, static_cast<const float*>(img), pos, cols, ldk, rows,
+                           nb, c_img, cin, H, W, f, rb);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -81,7 +89,7 @@ int launch_obs_im2col(const float* obs, float* cols, int ldk, int64_t rows, int 
     const int rb = gather_rb(cin, f);
     const size_t lds = (size_t)rb * cin * f * f * sizeof(float);
     if (lds > 64 * 1024) return MARL_ELIMIT;
-    hipLaunchKernelGGL((gather_im2col_kernel<true>), dim3((unsigned)cdiv(rows, rb)), dim3(256),
+    hipLaunchKernelGGL((gather_im2col_kernel<true, float>), dim3((unsigned)cdiv(rows, rb)), dim3(256),
                        lds, st, obs, (const int32_t*)nullptr, cols, ldk, rows, 1, c_img, cin, 0, 0,
                        f, rb);
     MARL_LAUNCH_CHECK();

@@ -265,8 +265,8 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
 // ---------------------------------------------------------------------------
 // Patch gather fused with the first layer's im2col: img [Nb,Cimg,H,W], pos int32 [R,2]
 // -> cols [R * P, ldk], k = (kh*3+kw)*cin + ci, P = oh*ow, oh = (f-1)/2+1.
-int launch_gather_im2col(const float* img, const int32_t* pos, float* cols, int ldk, int na,
-                         int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
+int launch_gather_im2col(const void* img, int img_u8, const int32_t* pos, float* cols, int ldk,
+                         int na, int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
 // same but from pre-gathered patches obs [R, c_img, f, f] (standalone step API)
 int launch_obs_im2col(const float* obs, float* cols, int ldk, int64_t rows, int c_img, int cin,
                       int f, hipStream_t st);

@@ -449,7 +449,8 @@ static int gemm2(const Ctx& c, const GemmProb& p0, const GemmProb& p1) {
 struct StepIn {
     const float* obs = nullptr;       // standalone API: pre-gathered patches
     const float* npos = nullptr;      // standalone API: normalised positions
-    const float* img = nullptr;
+    const void* img = nullptr;
+    int img_u8 = 0;
 };
 
 static bool use_panels(const Dims& d) {
@@ -472,8 +473,8 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
         MARL_TRY(launch_obs_im2col(in.obs, c.at(c.e.COLS[0], t), d.ldk[0], d.R, d.c_img, d.ch[0],
                                    d.f, st));
     else
-        MARL_TRY(launch_gather_im2col(in.img, c.POSs(t), c.at(c.e.COLS[0], t), d.ldk[0], d.na, d.nb,
-                                      d.c_img, d.ch[0], d.H, d.W, d.f, st));
+        MARL_TRY(launch_gather_im2col(in.img, in.img_u8, c.POSs(t), c.at(c.e.COLS[0], t), d.ldk[0],
+                                      d.na, d.nb, d.c_img, d.ch[0], d.H, d.W, d.f, st));
     for (int l = 0; l < d.L; ++l) {
         const int co = d.ch[l + 1];
         const int64_t rows = d.R * d.P[l];
@@ -1219,7 +1220,7 @@ int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_
 }
 
 int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
-                         const float* img, const int64_t* pos0, const float* h0, const float* c0,
+                         const void* img, const int64_t* pos0, const float* h0, const float* c0,
                          const float* hc0, const float* cc0, const float* noise,
                          const int64_t* forced_actions, float* step_preds, float* step_logp,
                          float* step_values, int64_t* step_pos, int64_t* step_actions, int train,
@@ -1236,6 +1237,7 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
     MARL_TRY(load_state(c, h0, c0, hc0, cc0, nullptr));
     StepIn in;
     in.img = img;
+    in.img_u8 = cfg->img_u8 != 0;
     const bool side = use_side_stream();
     Ctx c2 = c;
     if (side) {

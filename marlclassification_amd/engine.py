@@ -89,7 +89,8 @@ class ModelSpec:
         default_factory=lambda: [[1, 0], [-1, 0], [0, 1], [0, -1]]
     )
 
-    def config(self, nb_agents: int, batch: int, nb_steps: int, img_c: int, h: int, w: int) -> MarlConfig:
+    def config(self, nb_agents: int, batch: int, nb_steps: int, img_c: int, h: int, w: int,
+               img_u8: bool = False) -> MarlConfig:
         if self.ft_extr not in CNN_SPECS:
             raise ValueError(
                 f'feature extractor "{self.ft_extr}" has no HIP implementation '
@@ -112,6 +113,7 @@ class ModelSpec:
         cfg.nlb, cfg.nla = self.nlb, self.nla
         for j, (d0, d1) in enumerate(self.actions):
             cfg.actions[j][0], cfg.actions[j][1] = d0, d1
+        cfg.img_u8 = int(img_u8)
         return cfg
 
     @property
@@ -164,11 +166,12 @@ class HipEngine:
         self._packed_version: Optional[int] = None
 
     # -- configuration / workspaces -------------------------------------------------
-    def configure(self, nb_agents: int, batch: int, nb_steps: int, img_shape: Sequence[int]) -> MarlConfig:
-        key = (nb_agents, batch, nb_steps, tuple(img_shape))
+    def configure(self, nb_agents: int, batch: int, nb_steps: int, img_shape: Sequence[int],
+                  img_u8: bool = False) -> MarlConfig:
+        key = (nb_agents, batch, nb_steps, tuple(img_shape), bool(img_u8))
         if key != self._cfg_key:
             c, h, w = img_shape
-            self.cfg = self.spec.config(nb_agents, batch, nb_steps, c, h, w)
+            self.cfg = self.spec.config(nb_agents, batch, nb_steps, c, h, w, img_u8)
             self._cfg_key = key
         assert self.cfg is not None
         return self.cfg
@@ -221,7 +224,7 @@ class HipEngine:
         assert cfg is not None
         na, nb, ns = cfg.nb_agents, cfg.batch, cfg.nb_steps
         dev = self.device
-        img = _need(img, th.float32, "img")
+        img = _need(img, th.uint8 if cfg.img_u8 else th.float32, "img")
         pos0 = _need(pos0, th.int64, "pos0")
         h0, c0, hc0, cc0 = (_need(t, th.float32, n) for t, n in
                             ((h0, "h0"), (c0, "c0"), (hc0, "hc0"), (cc0, "cc0")))

@@ -1,0 +1,106 @@
+"""``train_main``: the reference's training driver (train.py:18-168) on the HIP path -
+same configs, same output tree (``marl.json``, ``class_to_idx.json``,
+``models/nn_models_epoch_{e}.pt`` with reference state-dict keys).  MLflow is optional (not
+installed here); images are uploaded as uint8 (data.py).  Multi-GPU: launch with
+``torchrun --nproc-per-node N -m marlclassification_amd ...``; every rank trains on its
+shard of each batch and gradients are all-reduced over RCCL."""
+
+import json
+import os
+from os.path import exists, isdir, join
+from typing import Dict, Optional
+
+import torch as th
+from torch.utils.data import DataLoader, Subset
+
+from .config import MainConfig, ModelConfig, TrainConfig
+from .core import EpisodeSampler
+from .data import ImageFolderU8, SyntheticImages
+from .parallel import GradAllReduce, shard_bounds
+from .training import Trainer
+
+
+def _dataset(model_config: ModelConfig, train_config: TrainConfig):
+    root = train_config.resources_dir
+    if root == "synthetic" or not exists(root):
+        channels = 1 if model_config.ft_extr_str == "mnist" else 3
+        return SyntheticImages(max(4 * train_config.batch_size, 64), channels, train_config.img_size,
+                               model_config.nb_class)
+    return ImageFolderU8(root)
+
+
+class _Sharded:
+    """Every rank sees the same batches (same seed) and keeps its contiguous shard."""
+
+    def __init__(self, loader: DataLoader, rank: int, world: int) -> None:
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __iter__(self):
+        for x, y in self.loader:
+            n = (x.shape[0] // self.world) * self.world
+            if n == 0:
+                continue
+            lo, hi = shard_bounds(n, self.rank, self.world)
+            yield x[lo:hi], y[lo:hi]
+
+
+def train_main(main_config: MainConfig, model_config: ModelConfig, train_config: TrainConfig,
+               metric_logger=None) -> Trainer:
+    assert model_config.state_dim == 2, "the HIP path implements 2-D images (state_dim == 2)"
+    output_dir = train_config.output_dir
+    model_dir = join(output_dir, "models")
+    os.makedirs(model_dir, exist_ok=True)
+    if not isdir(model_dir):
+        raise NotADirectoryError(f'"{model_dir}" is not a directory.')
+    if not main_config.cuda:
+        raise RuntimeError("this implementation only runs on the GPU: pass --cuda")
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = "RANK" in os.environ and world > 1
+    device = th.device("cuda", local_rank)
+    th.cuda.set_device(device)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    nn_models, marl_m, env = model_config.build_marl(main_config.nb_agent)
+    dataset = _dataset(model_config, train_config)
+    if rank == 0:
+        model_config.save_marl_config(join(output_dir, "marl.json"))
+        with open(join(output_dir, "class_to_idx.json"), "w", encoding="utf-8") as f:
+            json.dump(dataset.class_to_idx, f)
+    nn_models.to(device)
+    if distributed:  # identical initial weights on every rank
+        for p in nn_models.parameters():
+            dist.broadcast(p.data, src=0)
+
+    g = th.Generator().manual_seed(0)  # same split and shuffle on every rank
+    idx = th.randperm(len(dataset), generator=g)
+    cut = int(0.85 * idx.shape[0])
+    loaders = []
+    for part in (idx[:cut].tolist(), idx[cut:].tolist()):
+        dl = DataLoader(Subset(dataset, part), batch_size=train_config.batch_size, shuffle=True,
+                        num_workers=0, drop_last=False, pin_memory=True,
+                        generator=th.Generator().manual_seed(1))
+        loaders.append(_Sharded(dl, rank, world) if distributed else dl)
+
+    sampler = EpisodeSampler(marl_m, env, main_config.step)
+    trainer = Trainer(nn_models, marl_m.nb_class, train_config.learning_rate, train_config.gamma,
+                      metric_logger=metric_logger if rank == 0 else None,
+                      allreduce=GradAllReduce(world) if distributed else None)
+    for e in range(train_config.nb_epoch):
+        trainer.train_epoch(loaders[0], e, sampler)
+        conf = trainer.eval_epoch(loaders[1], e, sampler)
+        if rank == 0:
+            m: Dict[str, float] = trainer.metrics()
+            m["eval_prec"] = conf.precision().mean().item()
+            m["eval_recs"] = conf.recall().mean().item()
+            print(f"epoch {e}: " + ", ".join(f"{k}={v:.4f}" for k, v in m.items()), flush=True)
+            th.save(nn_models.state_dict(), join(model_dir, f"nn_models_epoch_{e}.pt"))
+    if distributed:
+        dist.destroy_process_group()
+    return trainer

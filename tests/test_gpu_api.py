@@ -168,3 +168,41 @@ def test_eval_epoch_and_state_dict_roundtrip(device, tmp_path):
     th.save(model.state_dict(), path)
     sd = th.load(path, map_location="cpu")
     assert list(sd) == list(g.params) and all(th.equal(sd[k], g.params[k]) for k in sd)
+
+
+def test_uint8_images_on_device_to_tensor(device):
+    """a uint8 batch is converted (x / 255, torchvision ToTensor) inside the
+    gather kernel; the episode equals the one on the pre-converted fp32 batch bit for bit."""
+    g = Golden("g1_conftest")
+    model, sampler = _golden_sampler(g, device)
+    img_u8 = (g.img * 255).round().to(th.uint8)
+    img_f = img_u8.to(th.float32).div(255)
+    with th.no_grad():
+        a = sampler.run_episode(img_u8.to(device))
+        b = sampler.run_episode(img_f.to(device))
+    assert th.equal(a.step_pos, b.step_pos)
+    assert th.equal(a.step_preds, b.step_preds) and th.equal(a.step_values, b.step_values)
+
+
+def test_train_main_cli_end_to_end(device, tmp_path):
+    """the reference's command line drives the HIP path; the output tree holds
+    marl.json, class_to_idx.json and per-epoch state dicts with reference keys."""
+    import json
+
+    from marlclassification_amd.__main__ import main
+    from oracle import marl_oracle as mo
+
+    out = tmp_path / "run"
+    argv = (f"-a 3 --step 5 --cuda --run-id smoke train --ft-extr mnist --f 6 --img-size 28 --nb 64 "
+            f"--na 64 --nm 16 --nmo 24 --nd 8 --nlb 96 --nla 96 --batch-size 16 --nb-epoch 2 "
+            f"--lr 1e-3 --res-folder synthetic -o {out}").split()
+    main(argv)
+    cfg = json.loads((out / "marl.json").read_text())
+    assert cfg["window_size"] == 6 and cfg["actions"] == [[1, 0], [-1, 0], [0, 1], [0, -1]]
+    assert (out / "class_to_idx.json").exists()
+    sd = th.load(out / "models" / "nn_models_epoch_1.pt", map_location="cpu")
+    ocfg = mo.OracleConfig("mnist", 6, 64, 64, 16, 24, 8, 10, 96, 96)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == mo.param_shapes(ocfg)
+    assert all(bool(th.isfinite(v).all()) for v in sd.values())
+    sd0 = th.load(out / "models" / "nn_models_epoch_0.pt", map_location="cpu")
+    assert any(not th.equal(sd[k], sd0[k]) for k in sd), "weights did not change between epochs"
