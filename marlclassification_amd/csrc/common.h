@@ -81,8 +81,10 @@ int profile_end(double* total_ms, int* launches);
 
 // C[NI,NJ] = sum_r A[r,i] * B[r,j]  (weight gradients; contraction over rows).
 size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows);
+// colsum_out (nullable): also writes out[i] = sum_r A[r,i] (the matching bias gradient)
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
-                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st);
+                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
+                   float* colsum_out = nullptr);
 
 // ---------------------------------------------------------------------------
 // row-wise kernels (rowops.hip)

@@ -837,10 +837,11 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
 // ---------------------------------------------------------------------------
 // backward helpers
 // ---------------------------------------------------------------------------
+// weight gradient gp(pidx) = A^T B over `rows` rows; bias (nullable) = column sums of A
 static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, int pidx, int ni,
-              int nj, int64_t rows) {
+              int nj, int64_t rows, float* bias = nullptr) {
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
-                          c.e.tns_bytes, c.st);
+                          c.e.tns_bytes, c.st, bias);
 }
 static int csum(const Ctx& c, const float* x, int ld, int64_t rows, int n, float* out) {
     return launch_colsum(x, ld, rows, n, out, c.at(c.e.CSUM), c.st);
@@ -878,12 +879,10 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         MARL_TRY(launch_fill(c.at(c.e.GPRED), NR * d.ld_nC, 0.f, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.GPRED), d.ld_nC, c.wt(MARL_P_PRE_W1), p4(d.nC), d.nC,
                                 c.at(c.e.DAQ1), d.ld_nlb, (int)NR, d.nlb)));
-    MARL_TRY(tn(c, c.at(c.e.GPRED), d.ld_nC, c.at(c.e.AQ1), d.ld_nlb, MARL_P_PRE_W1, d.nC, d.nlb, NR));
-    MARL_TRY(csum(c, c.at(c.e.GPRED), d.ld_nC, NR, d.nC, grads[MARL_P_PRE_B1]));
+    MARL_TRY(tn(c, c.at(c.e.GPRED), d.ld_nC, c.at(c.e.AQ1), d.ld_nlb, MARL_P_PRE_W1, d.nC, d.nlb, NR, grads[MARL_P_PRE_B1]));
     MARL_TRY(ln_bwd(c, c.at(c.e.DAQ1), d.ld_nlb, c.at(c.e.ZQ1), d.ld_nlb, c.at(c.e.STQ1),
                     MARL_P_PRE_LNW, MARL_P_PRE_LNB, NR, d.nlb, grads, 0));
-    MARL_TRY(tn(c, c.at(c.e.DAQ1), d.ld_nlb, c.Hs(1), d.ld_nb, MARL_P_PRE_W0, d.nlb, d.n_b, NR));
-    MARL_TRY(csum(c, c.at(c.e.DAQ1), d.ld_nlb, NR, d.nlb, grads[MARL_P_PRE_B0]));
+    MARL_TRY(tn(c, c.at(c.e.DAQ1), d.ld_nlb, c.Hs(1), d.ld_nb, MARL_P_PRE_W0, d.nlb, d.n_b, NR, grads[MARL_P_PRE_B0]));
     // critic head (networks/policy.py:23-27)
     if (g_values)
         MARL_TRY(launch_copy2d(g_values, 1, c.at(c.e.DVAL), 4, NR, 1, st));
@@ -891,23 +890,19 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         MARL_TRY(launch_fill(c.at(c.e.DVAL), NR * 4, 0.f, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DVAL), 4, c.wt(MARL_P_CRI_W1), 4, 1, c.at(c.e.DAC1),
                                 d.ld_nla, (int)NR, d.nla)));
-    MARL_TRY(tn(c, c.at(c.e.DVAL), 4, c.at(c.e.AC1), d.ld_nla, MARL_P_CRI_W1, 1, d.nla, NR));
-    MARL_TRY(csum(c, c.at(c.e.DVAL), 4, NR, 1, grads[MARL_P_CRI_B1]));
+    MARL_TRY(tn(c, c.at(c.e.DVAL), 4, c.at(c.e.AC1), d.ld_nla, MARL_P_CRI_W1, 1, d.nla, NR, grads[MARL_P_CRI_B1]));
     MARL_TRY(ln_bwd(c, c.at(c.e.DAC1), d.ld_nla, c.at(c.e.ZC1), d.ld_nla, c.at(c.e.STC1),
                     MARL_P_CRI_LNW, MARL_P_CRI_LNB, NR, d.nla, grads, 0));
-    MARL_TRY(tn(c, c.at(c.e.DAC1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_CRI_W0, d.nla, d.n_a, NR));
-    MARL_TRY(csum(c, c.at(c.e.DAC1), d.ld_nla, NR, d.nla, grads[MARL_P_CRI_B0]));
+    MARL_TRY(tn(c, c.at(c.e.DAC1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_CRI_W0, d.nla, d.n_a, NR, grads[MARL_P_CRI_B0]));
     // policy head: logp = log softmax(logits)[a]  (networks/policy.py:12-16, core/agent.py:57-61)
     MARL_TRY(launch_policy_dlogits(g_logp, c.PROBSs(0), c.ACTs(0), c.at(c.e.DLOG), d.ld_nA, NR,
                                    d.nA, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DLOG), d.ld_nA, c.wt(MARL_P_POL_W1), p4(d.nA), d.nA,
                                 c.at(c.e.DAP1), d.ld_nla, (int)NR, d.nla)));
-    MARL_TRY(tn(c, c.at(c.e.DLOG), d.ld_nA, c.at(c.e.AP1, 0), d.ld_nla, MARL_P_POL_W1, d.nA, d.nla, NR));
-    MARL_TRY(csum(c, c.at(c.e.DLOG), d.ld_nA, NR, d.nA, grads[MARL_P_POL_B1]));
+    MARL_TRY(tn(c, c.at(c.e.DLOG), d.ld_nA, c.at(c.e.AP1, 0), d.ld_nla, MARL_P_POL_W1, d.nA, d.nla, NR, grads[MARL_P_POL_B1]));
     MARL_TRY(ln_bwd(c, c.at(c.e.DAP1), d.ld_nla, c.at(c.e.ZP1, 0), d.ld_nla, c.at(c.e.STP1, 0),
                     MARL_P_POL_LNW, MARL_P_POL_LNB, NR, d.nla, grads, 0));
-    MARL_TRY(tn(c, c.at(c.e.DAP1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_POL_W0, d.nla, d.n_a, NR));
-    MARL_TRY(csum(c, c.at(c.e.DAP1), d.ld_nla, NR, d.nla, grads[MARL_P_POL_B0]));
+    MARL_TRY(tn(c, c.at(c.e.DAP1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_POL_W0, d.nla, d.n_a, NR, grads[MARL_P_POL_B0]));
     // gradients reaching h_t / h^_t from the heads, all steps at once
     {
         GemmProb ph = gemm_prob(c.at(c.e.DAQ1), d.ld_nlb, c.wt(MARL_P_PRE_W0), d.ld_nlb, d.nlb,
@@ -1055,16 +1050,12 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     }
 
     // ---- weight gradients of the recurrent chain: one contraction over all steps -------
-    MARL_TRY(tn(c, c.at(c.e.DDBAR), d.ld_nmo, c.at(c.e.AD1, 0), d.ld_nm2, MARL_P_DEC_W1, d.n_mo, d.nm2, NR));
-    MARL_TRY(csum(c, c.at(c.e.DDBAR), d.ld_nmo, NR, d.n_mo, grads[MARL_P_DEC_B1]));
-    MARL_TRY(tn(c, c.at(c.e.DAD1), d.ld_nm2, c.at(c.e.MBAR, 0), d.ld_nm, MARL_P_DEC_W0, d.nm2, d.n_m, NR));
-    MARL_TRY(csum(c, c.at(c.e.DAD1), d.ld_nm2, NR, d.nm2, grads[MARL_P_DEC_B0]));
+    MARL_TRY(tn(c, c.at(c.e.DDBAR), d.ld_nmo, c.at(c.e.AD1, 0), d.ld_nm2, MARL_P_DEC_W1, d.n_mo, d.nm2, NR, grads[MARL_P_DEC_B1]));
+    MARL_TRY(tn(c, c.at(c.e.DAD1), d.ld_nm2, c.at(c.e.MBAR, 0), d.ld_nm, MARL_P_DEC_W0, d.nm2, d.n_m, NR, grads[MARL_P_DEC_B0]));
     if (ns > 1) {
         const int64_t er = (int64_t)(ns - 1) * d.R;  // the last step's message is never read
-        MARL_TRY(tn(c, c.at(c.e.DZE2), d.ld_nm, c.at(c.e.AE1, 0), d.ld_nm2, MARL_P_ENC_W1, d.n_m, d.nm2, er));
-        MARL_TRY(csum(c, c.at(c.e.DZE2), d.ld_nm, er, d.n_m, grads[MARL_P_ENC_B1]));
-        MARL_TRY(tn(c, c.at(c.e.DAE1), d.ld_nm2, c.Hs(1), d.ld_nb, MARL_P_ENC_W0, d.nm2, d.n_b, er));
-        MARL_TRY(csum(c, c.at(c.e.DAE1), d.ld_nm2, er, d.nm2, grads[MARL_P_ENC_B0]));
+        MARL_TRY(tn(c, c.at(c.e.DZE2), d.ld_nm, c.at(c.e.AE1, 0), d.ld_nm2, MARL_P_ENC_W1, d.n_m, d.nm2, er, grads[MARL_P_ENC_B1]));
+        MARL_TRY(tn(c, c.at(c.e.DAE1), d.ld_nm2, c.Hs(1), d.ld_nb, MARL_P_ENC_W0, d.nm2, d.n_b, er, grads[MARL_P_ENC_B0]));
     } else {
         const int enc[] = {MARL_P_ENC_B0, MARL_P_ENC_LN0W, MARL_P_ENC_LN0B, MARL_P_ENC_B1,
                            MARL_P_ENC_LN1W, MARL_P_ENC_LN1B};
@@ -1073,12 +1064,10 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         MARL_TRY(launch_fill(c.gp(MARL_P_ENC_W1), (int64_t)d.n_m * c.w.ldp[MARL_P_ENC_W1], 0.f, st));
     }
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.at(c.e.U, 0), d.ld_nin, MARL_P_LB_WIH, 4 * d.n_b, d.nin, NR));
-    MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR));
-    MARL_TRY(csum(c, c.at(c.e.GB, 0), d.ld_gb, NR, 4 * d.n_b, grads[MARL_P_LB_BIH]));
+    MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR, grads[MARL_P_LB_BIH]));
     MARL_TRY(launch_copy2d(grads[MARL_P_LB_BIH], 0, grads[MARL_P_LB_BHH], 0, 1, 4 * d.n_b, st));
     MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.at(c.e.U, 0), d.ld_nin, MARL_P_LA_WIH, 4 * d.n_a, d.nin, NR));
-    MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.HCs(0), d.ld_na, MARL_P_LA_WHH, 4 * d.n_a, d.n_a, NR));
-    MARL_TRY(csum(c, c.at(c.e.GA, 0), d.ld_ga, NR, 4 * d.n_a, grads[MARL_P_LA_BIH]));
+    MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.HCs(0), d.ld_na, MARL_P_LA_WHH, 4 * d.n_a, d.n_a, NR, grads[MARL_P_LA_BIH]));
     MARL_TRY(launch_copy2d(grads[MARL_P_LA_BIH], 0, grads[MARL_P_LA_BHH], 0, 1, 4 * d.n_a, st));
 
     // ---- dU for all steps, then position embedding and CNN backward -------------------
@@ -1091,8 +1080,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     MARL_TRY(ln_bwd(c, c.at(c.e.DU) + d.nf + d.n_mo, d.ld_nin, c.at(c.e.ZPOS, 0), d.ld_nd,
                     c.at(c.e.STPOS, 0), MARL_P_POS_LNW, MARL_P_POS_LNB, NR, d.n_d, grads, 0,
                     c.at(c.e.DZPOS), d.ld_nd));
-    MARL_TRY(tn(c, c.at(c.e.DZPOS), d.ld_nd, c.at(c.e.NPOS, 0), 4, MARL_P_POS_W, d.n_d, 2, NR));
-    MARL_TRY(csum(c, c.at(c.e.DZPOS), d.ld_nd, NR, d.n_d, grads[MARL_P_POS_B]));
+    MARL_TRY(tn(c, c.at(c.e.DZPOS), d.ld_nd, c.at(c.e.NPOS, 0), 4, MARL_P_POS_W, d.n_d, 2, NR, grads[MARL_P_POS_B]));
     {
         const float* da = c.at(c.e.DU);
         int64_t ldda = d.ld_nin;
@@ -1106,8 +1094,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                                         d.P[l], co, d.grp[l], st));
             MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR, co), co, grads[4 * l + 2],
                                           grads[4 * l + 3], 0, st));
-            MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows));
-            MARL_TRY(csum(c, dz, co, rows, co, grads[4 * l + 1]));
+            MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
             if (l > 0) {
                 MARL_TRY(gemm1(c, gemm_prob(dz, co, c.wt(4 * l), p4(co), co, c.at(c.e.DCOLS[l]),
                                             d.ldk[l], (int)rows, d.K[l])));

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int ldb,
                                                       float* __restrict__ out, int ldo,
                                                       int64_t out_split_stride, int NI, int NJ,
-                                                      int64_t rows, int64_t rows_per_split) {
+                                                      int64_t rows, int64_t rows_per_split,
+                                                      float* __restrict__ csum) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_CH = BK * (BM / 4) / 256;
@@ -304,6 +305,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
     float4 ra0, ra1, rb0, rb1;
     float mk0 = 1.f, mk1 = 1.f;
+    // column sums of A (the bias gradient that goes with this weight gradient): taken for
+    // free from the staged A tiles by the workgroups of the first column-tile
+    const bool do_csum = csum != nullptr && blockIdx.y == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define MARL_TN_LOAD(tile_)                                                            \
     {                                                                                  \
         const int64_t base_ = r_begin + (int64_t)(tile_) * BK;                         \
@@ -330,6 +335,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         v_.y *= mk_;                                                                   \
         v_.z *= mk_;                                                                   \
         v_.w *= mk_;                                                                   \
+        if (do_csum) {                                                                 \
+            cs.x += v_.x;                                                              \
+            cs.y += v_.y;                                                              \
+            cs.z += v_.z;                                                              \
+            cs.w += v_.w;                                                              \
+        }                                                                              \
         *reinterpret_cast<float4*>(As_ + (c_ / (BM / 4)) * BM + (c_ % (BM / 4)) * 4) = v_; \
         *reinterpret_cast<float4*>(Bs_ + (c_ / (BN / 4)) * BN + (c_ % (BN / 4)) * 4) = rb_; \
     }
@@ -366,6 +377,32 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #undef MARL_TN_LOAD
 #undef MARL_TN_STORE
 
+    if (do_csum) {  // threads with equal (tid % (BM/4)) staged the same 4 columns
+        constexpr int CPR = BM / 4;     // column chunks per tile row
+        constexpr int SH = 256 / CPR;   // threads sharing a chunk
+        __syncthreads();
+        float4* sh4 = reinterpret_cast<float4*>(smem);
+        sh4[(tid / CPR) * CPR + (tid % CPR)] = cs;
+        __syncthreads();
+        if (tid < CPR) {
+            float4 t = sh4[tid];
+#pragma unroll
+            for (int q = 1; q < SH; ++q) {
+                const float4 u = sh4[q * CPR + tid];
+                t.x += u.x;
+                t.y += u.y;
+                t.z += u.z;
+                t.w += u.w;
+            }
+            float* co = csum + (size_t)blockIdx.z * NI;
+            const int ic = i0 + tid * 4;
+            if (ic < NI) co[ic] = t.x;
+            if (ic + 1 < NI) co[ic + 1] = t.y;
+            if (ic + 2 < NI) co[ic + 2] = t.z;
+            if (ic + 3 < NI) co[ic + 3] = t.w;
+        }
+    }
+
     float* o = out + (size_t)blockIdx.z * out_split_stride;
     const int row_h = 4 * (lane >> 5);
 #pragma unroll
@@ -382,8 +419,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int64_t split_stride,
-                                     int splits, float* __restrict__ c, int ldc, int NI, int NJ) {
+// Fixed-order reduction of the split-K slabs.  Workgroups past `main_blocks` reduce the
+// column-sum partials instead: one wave per column, lanes strided over the splits.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+    const float* __restrict__ part, int64_t split_stride, int splits, float* __restrict__ c,
+    int ldc, int NI, int NJ, const float* __restrict__ csum_part, float* __restrict__ csum_out,
+    int main_blocks) {
+    if ((int)blockIdx.x >= main_blocks) {
+        const int i = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
+        if (i >= NI) return;
+        const int lane = threadIdx.x & 63;
+        float s = 0.f;
+        for (int z = lane; z < splits; z += 64) s += csum_part[(size_t)z * NI + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) csum_out[i] = s;
+        return;
+    }
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)NI * NJ) return;
     const int i = (int)(idx / NJ), j = (int)(idx % NJ);
@@ -589,11 +641,13 @@ static TnPlan tn_plan(int ni, int nj, int64_t rows) {
 
 size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows) {
     TnPlan p = tn_plan(ni, nj, rows);
-    return p.splits > 1 ? (size_t)p.splits * ni * nj * sizeof(float) : 0;
+    // split partials of the product + of the optional column sums
+    return p.splits > 1 ? ((size_t)p.splits * ni * nj + (size_t)p.splits * ni) * sizeof(float) : 0;
 }
 
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
-                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st) {
+                   int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
+                   float* colsum_out) {
     if (!a || !b || !c || ni <= 0 || nj <= 0 || rows <= 0 || (lda & 3) || (ldb & 3) ||
         lda < p4(ni) || ldb < p4(nj) || (reinterpret_cast<uintptr_t>(a) & 15) ||
         (reinterpret_cast<uintptr_t>(b) & 15)) {
@@ -606,7 +660,7 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     int ldo = ldc;
     int64_t stride = 0;
     if (p.splits > 1) {
-        if (!scratch || scratch_bytes < (size_t)p.splits * ni * nj * sizeof(float)) {
+        if (!scratch || scratch_bytes < gemm_tn_scratch_bytes(ni, nj, rows)) {
             set_error("gemm_tn: scratch too small");
             return MARL_ESIZE;
         }
@@ -614,20 +668,25 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         ldo = nj;
         stride = (int64_t)ni * nj;
     }
+    float* csum = colsum_out;  // split partials live behind the product partials
+    if (colsum_out && p.splits > 1) csum = scratch + (size_t)p.splits * ni * nj;
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
     prof_before(2, st);
     if (p.bm == 128)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split);
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split);
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum);
     prof_after(2, st);
     MARL_LAUNCH_CHECK();
     if (p.splits > 1) {
         const int64_t n = (int64_t)ni * nj;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st,
-                           scratch, stride, p.splits, c, ldc, ni, nj);
+        const int main_blocks = (int)cdiv(n, 256);
+        const int extra = colsum_out ? (int)cdiv(ni, 4) : 0;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(main_blocks + extra)), dim3(256), 0,
+                           st, scratch, stride, p.splits, c, ldc, ni, nj,
+                           colsum_out ? csum : nullptr, colsum_out, main_blocks);
         MARL_LAUNCH_CHECK();
     }
     return MARL_OK;
