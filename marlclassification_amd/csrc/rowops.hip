@@ -3,6 +3,7 @@
 // bounded move, deterministic reductions, weight (un)packing and Adam.
 // One 64-lane wave owns a row wherever a row reduction is needed.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -405,6 +406,112 @@ __global__ __launch_bounds__(1024) void gn_silu_bwd_kernel(
     }
 }
 
+// Coalesced variant for power-of-two channel counts: a wave walks the NHWC row in flat
+// order (64 consecutive floats per load), so every lane keeps ONE channel (C <= 64) or the
+// channels lane + 64u (C = 128, 256).  Group sums come from xor-shuffles over the lane bits
+// that stay inside a group, channel sums (dgamma / dbeta) over the position bits.
+template <int U>  // channels per lane = max(1, C / 64)
+__global__ __launch_bounds__(1024) void gn_silu_bwd_flat_kernel(
+    const float* __restrict__ da, int64_t ldda, int da_chw, const float* __restrict__ z,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dz, float* __restrict__ part,
+    int64_t rows, int P, int C, int G, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [waves][2][C]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    float* ga = sacc + (size_t)wave * 2 * C;
+    float* gb = ga + C;
+    for (int c = lane; c < C; c += 64) {
+        ga[c] = 0.f;
+        gb[c] = 0.f;
+    }
+    const int Cg = C / G;
+    const int E = P * C;
+    const int lc = C < 64 ? C : 64;  // lanes per position
+    const float inv_cnt = 1.0f / (float)(P * Cg);
+    float gm[U], bt[U];
+    int ch[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ch[u] = (lane % lc) + 64 * u;
+        gm[u] = gamma[ch[u]];
+        bt[u] = beta[ch[u]];
+    }
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = ((int64_t)blockIdx.x * nwaves + wave) * rpw + rr;
+        if (row >= rows) break;
+        const float* zr = z + row * (int64_t)E;
+        const float* dar = da + row * ldda;
+        float* dzr = dz + row * (int64_t)E;
+        float mean[U], rstd[U], s1[U], s2[U], pg[U], pb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int g = ch[u] / Cg;
+            mean[u] = stats[(row * G + g) * 2];
+            rstd[u] = stats[(row * G + g) * 2 + 1];
+            s1[u] = s2[u] = pg[u] = pb[u] = 0.f;
+        }
+        // element e = lane + 64 * i: position e / C, channel e % C (fixed per lane and u)
+        for (int e0 = 0; e0 < E; e0 += 64 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + lane + 64 * u;
+                if (e < E) {
+                    const int pos = e / C;
+                    const float xh = (zr[e] - mean[u]) * rstd[u];
+                    const float dav = dar[da_chw ? (int64_t)ch[u] * P + pos : (int64_t)e];
+                    const float dy = dav * silu_grad(gm[u] * xh + bt[u]);
+                    const float dxh = dy * gm[u];
+                    s1[u] += dxh;
+                    s2[u] += dxh * xh;
+                    pg[u] += dy * xh;
+                    pb[u] += dy;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // group sums: lanes of the same group = same bits above log2(Cg) within the
+            // position (when Cg <= 64) x all position bits
+            for (int o = 1; o < Cg && o < 64; o <<= 1) {
+                s1[u] += __shfl_xor(s1[u], o);
+                s2[u] += __shfl_xor(s2[u], o);
+            }
+            for (int o = lc; o < 64; o <<= 1) {
+                s1[u] += __shfl_xor(s1[u], o);
+                s2[u] += __shfl_xor(s2[u], o);
+                pg[u] += __shfl_xor(pg[u], o);
+                pb[u] += __shfl_xor(pb[u], o);
+            }
+            if (lane < lc) {  // single owner per channel
+                ga[ch[u]] += pg[u];
+                gb[ch[u]] += pb[u];
+            }
+        }
+        for (int e0 = 0; e0 < E; e0 += 64 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + lane + 64 * u;
+                if (e < E) {
+                    const int pos = e / C;
+                    const float xh = (zr[e] - mean[u]) * rstd[u];
+                    const float dav = dar[da_chw ? (int64_t)ch[u] * P + pos : (int64_t)e];
+                    const float dxh = dav * silu_grad(gm[u] * xh + bt[u]) * gm[u];
+                    dzr[e] = rstd[u] * (dxh - s1[u] * inv_cnt - xh * s2[u] * inv_cnt);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* p = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sacc[(size_t)w * 2 * C + c];
+        p[c] = t;
+    }
+}
+
 int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
                        const float* stats, const float* gamma, const float* beta, float* dz,
                        float* part, int64_t rows, int P, int C, int G, hipStream_t st) {
@@ -416,6 +523,22 @@ int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z
     }
     const int w = bwd_waves(C);
     const int rpw = bwd_rows_per_wave(rows, w);
+    const bool pow2 = (C & (C - 1)) == 0 && C <= 256 && C >= 4;
+    if (pow2 && !getenv("MARL_GN_OLD")) {
+        const dim3 grid((unsigned)gn_bwd_blocks(rows, C)), blk(64 * w);
+        const size_t lds = (size_t)w * 2 * C * sizeof(float);
+        if (C <= 64)
+            hipLaunchKernelGGL(gn_silu_bwd_flat_kernel<1>, grid, blk, lds, st, da, ldda, da_chw, z,
+                               stats, gamma, beta, dz, part, rows, P, C, G, rpw);
+        else if (C == 128)
+            hipLaunchKernelGGL(gn_silu_bwd_flat_kernel<2>, grid, blk, lds, st, da, ldda, da_chw, z,
+                               stats, gamma, beta, dz, part, rows, P, C, G, rpw);
+        else
+            hipLaunchKernelGGL(gn_silu_bwd_flat_kernel<4>, grid, blk, lds, st, da, ldda, da_chw, z,
+                               stats, gamma, beta, dz, part, rows, P, C, G, rpw);
+        MARL_LAUNCH_CHECK();
+        return MARL_OK;
+    }
     hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3((unsigned)gn_bwd_blocks(rows, C)), dim3(64 * w),
                        (size_t)w * 2 * C * sizeof(float), st, da, ldda, da_chw, z, stats, gamma,
                        beta, dz, part, rows, P, C, G, rpw);
