@@ -323,10 +323,75 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_kernel(const float* __restric
     }
 }
 
+// Flat-order forward for power-of-two channel counts <= 64 and rows of <= 64 * EPL
+// elements: the row is read ONCE into registers (coalesced), group statistics come from
+// xor-shuffles (lane bits inside the group x position bits), two-pass variance.
+template <int EPL>
+__global__ __launch_bounds__(256) void gn_silu_fwd_flat_kernel(
+    const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ out, int64_t ldo, int out_chw, float* __restrict__ stats, int64_t rows,
+    int P, int C, int G) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int Cg = C / G, E = P * C;
+    const int c = lane % C, g = c / Cg;
+    const float* zr = z + row * (int64_t)E;
+    float v[EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < E ? zr[e] : 0.f;
+        s += v[i];
+    }
+    for (int o = 1; o < Cg; o <<= 1) s += __shfl_xor(s, o);
+    for (int o = C; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)(P * Cg);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const float d = v[i] - mean;
+        q += (lane + 64 * i < E) ? d * d : 0.f;
+    }
+    for (int o = 1; o < Cg; o <<= 1) q += __shfl_xor(q, o);
+    for (int o = C; o < 64; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)(P * Cg) + 1e-5f);
+    const float gm = gamma[c], bt = beta[c];
+    float* orow = out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        if (e < E) {
+            const float y = (v[i] - mean) * rstd * gm + bt;
+            orow[out_chw ? (int64_t)c * P + e / C : (int64_t)e] = silu_f(y);
+        }
+    }
+    if (stats && lane < C && (lane % Cg) == 0) {
+        stats[(row * G + g) * 2] = mean;
+        stats[(row * G + g) * 2 + 1] = rstd;
+    }
+}
+
 int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
                        int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
                        hipStream_t st) {
     if (rows <= 0) return MARL_OK;
+    const int E = P * C;
+    if ((C & (C - 1)) == 0 && C >= 4 && C <= 64 && E <= 64 * 16 && !getenv("MARL_GN_OLD")) {
+        const dim3 grid((unsigned)cdiv(rows, 4)), blk(256);
+        if (E <= 64 * 4)
+            hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<4>, grid, blk, 0, st, z, gamma, beta, out, ldo,
+                               out_chw, stats, rows, P, C, G);
+        else if (E <= 64 * 9)
+            hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<9>, grid, blk, 0, st, z, gamma, beta, out, ldo,
+                               out_chw, stats, rows, P, C, G);
+        else
+            hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<16>, grid, blk, 0, st, z, gamma, beta, out,
+                               ldo, out_chw, stats, rows, P, C, G);
+        MARL_LAUNCH_CHECK();
+        return MARL_OK;
+    }
     hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, z,
                        gamma, beta, out, ldo, out_chw, stats, rows, P, C, G);
     MARL_LAUNCH_CHECK();
