@@ -110,9 +110,12 @@ int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float
 
 // GroupNorm + SiLU over NHWC rows: z [rows, P, C] -> a.  out_chw != 0 writes element
 // (pos, c) at out[row * ldo + c * P + pos] (reference Flatten order), else NHWC with ldo = P*C.
+// cols != null: additionally scatters the activations into the NEXT layer's im2col matrix
+// (3x3 stride 2 pad 1; hin = this layer's output side); out may then be null.
+int gn_fwd_im2col_supported(int P, int C);
 int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
                        int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
-                       hipStream_t st);
+                       hipStream_t st, float* cols = nullptr, int ldk = 0, int hin = 0);
 int gn_bwd_blocks(int64_t rows, int C);
 int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
                        const float* stats, const float* gamma, const float* beta, float* dz,

@@ -480,7 +480,12 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
         const int64_t rows = d.R * d.P[l];
         MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.COLS[l], t), d.ldk[l], c.wp(4 * l), d.ldk[l], d.K[l],
                                     c.at(c.e.Z[l], t), co, (int)rows, co, c.wp(4 * l + 1))));
-        if (l + 1 < d.L) {
+        if (l + 1 < d.L && gn_fwd_im2col_supported(d.P[l], co)) {
+            // GroupNorm + SiLU + the next layer's im2col in one pass (A_l is never materialised)
+            MARL_TRY(launch_gn_silu_fwd(c.at(c.e.Z[l], t), c.wp(4 * l + 2), c.wp(4 * l + 3), nullptr,
+                                        0, 0, c.at(c.e.GST[l], t), d.R, d.P[l], co, d.grp[l], st,
+                                        c.at(c.e.COLS[l + 1], t), d.ldk[l + 1], d.hw[l + 1]));
+        } else if (l + 1 < d.L) {
             MARL_TRY(launch_gn_silu_fwd(c.at(c.e.Z[l], t), c.wp(4 * l + 2), c.wp(4 * l + 3),
                                         c.at(c.e.A[l], t), (int64_t)d.P[l] * co, 0,
                                         c.at(c.e.GST[l], t), d.R, d.P[l], co, d.grp[l], st));

@@ -330,7 +330,7 @@ template <int EPL>
 __global__ __launch_bounds__(256) void gn_silu_fwd_flat_kernel(
     const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ out, int64_t ldo, int out_chw, float* __restrict__ stats, int64_t rows,
-    int P, int C, int G) {
+    int P, int C, int G, float* __restrict__ cols, int ldk, int hin) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -364,7 +364,27 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_flat_kernel(
         const int e = lane + 64 * i;
         if (e < E) {
             const float y = (v[i] - mean) * rstd * gm + bt;
-            orow[out_chw ? (int64_t)c * P + e / C : (int64_t)e] = silu_f(y);
+            const float av = silu_f(y);
+            if (out) orow[out_chw ? (int64_t)c * P + e / C : (int64_t)e] = av;
+            if (cols) {
+                // the next layer's im2col rows (3x3, stride 2, pad 1) straight from registers:
+                // input pixel (py, px) feeds output (oy, ox) through tap (kh, kw) when
+                // 2*oy - 1 + kh == py.  Padding taps are never written (the buffer is zero).
+                const int pos = e / C, py = pos / hin, px = pos % hin;
+                const int hout = (hin - 1) / 2 + 1;
+                float* crow = cols + row * (int64_t)hout * hout * ldk + c;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ty = py + 1 - kh;
+                    if (ty < 0 || (ty & 1) || (ty >> 1) >= hout) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int tx = px + 1 - kw;
+                        if (tx < 0 || (tx & 1) || (tx >> 1) >= hout) continue;
+                        crow[(int64_t)((ty >> 1) * hout + (tx >> 1)) * ldk + (kh * 3 + kw) * C] = av;
+                    }
+                }
+            }
         }
     }
     if (stats && lane < C && (lane % Cg) == 0) {
@@ -373,22 +393,31 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_flat_kernel(
     }
 }
 
+static bool gn_flat_ok(int P, int C) {
+    return (C & (C - 1)) == 0 && C >= 4 && C <= 64 && P * C <= 64 * 16 && !getenv("MARL_GN_OLD");
+}
+int gn_fwd_im2col_supported(int P, int C) { return gn_flat_ok(P, C) ? 1 : 0; }
+
 int launch_gn_silu_fwd(const float* z, const float* gamma, const float* beta, float* out,
                        int64_t ldo, int out_chw, float* stats, int64_t rows, int P, int C, int G,
-                       hipStream_t st) {
+                       hipStream_t st, float* cols, int ldk, int hin) {
     if (rows <= 0) return MARL_OK;
     const int E = P * C;
-    if ((C & (C - 1)) == 0 && C >= 4 && C <= 64 && E <= 64 * 16 && !getenv("MARL_GN_OLD")) {
+    if (cols && !gn_flat_ok(P, C)) {
+        set_error("fused GroupNorm + im2col needs a power-of-two channel count <= 64");
+        return MARL_ELIMIT;
+    }
+    if (gn_flat_ok(P, C)) {
         const dim3 grid((unsigned)cdiv(rows, 4)), blk(256);
         if (E <= 64 * 4)
             hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<4>, grid, blk, 0, st, z, gamma, beta, out, ldo,
-                               out_chw, stats, rows, P, C, G);
+                               out_chw, stats, rows, P, C, G, cols, ldk, hin);
         else if (E <= 64 * 9)
             hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<9>, grid, blk, 0, st, z, gamma, beta, out, ldo,
-                               out_chw, stats, rows, P, C, G);
+                               out_chw, stats, rows, P, C, G, cols, ldk, hin);
         else
             hipLaunchKernelGGL(gn_silu_fwd_flat_kernel<16>, grid, blk, 0, st, z, gamma, beta, out,
-                               ldo, out_chw, stats, rows, P, C, G);
+                               ldo, out_chw, stats, rows, P, C, G, cols, ldk, hin);
         MARL_LAUNCH_CHECK();
         return MARL_OK;
     }
