@@ -178,3 +178,58 @@ def test_step_api_matches_oracle(device):
     for a, b, n in zip(got, (so.probs, so.values, so.preds, so.msg, so.h, so.c, so.hc, so.cc),
                        ("probs", "values", "preds", "msg", "h", "c", "hc", "cc")):
         assert _maxerr(a, b) <= ATOL, n
+
+
+# ---- the other BASELINE.json configurations, at a batch the oracle finishes in seconds -------
+BIG_CASES = {
+    # C2: MNIST shapes at a larger batch (configs[1] uses batch 1024; 64 keeps the oracle fast)
+    "c2_mnist": (mo.OracleConfig("mnist", 6, 64, 64, 16, 24, 8, 10, 96, 96), 3, 64, 5, (3, 28, 28)),
+    # C4: AID 600x600, f=24, 4 conv layers (128 channels), stride-3 moves, 30 classes
+    "c4_aid": (mo.OracleConfig("aid", 24, 256, 256, 64, 96, 16, 30, 320, 320,
+                               actions=[[3, 0], [-3, 0], [0, 3], [0, -3]]), 16, 2, 16, (3, 600, 600)),
+    # C5: synthetic 1024x1024, 64 agents, 32 steps, f=32 (AidCnn + RESISC hidden sizes)
+    "c5_synth": (mo.OracleConfig("aid", 32, 256, 256, 64, 96, 16, 45, 384, 384,
+                                 actions=[[4, 0], [-4, 0], [0, 4], [0, -4]]), 64, 1, 32, (3, 1024, 1024)),
+}
+
+
+@pytest.mark.parametrize("tag", list(BIG_CASES))
+def test_other_baseline_configs_match_oracle(device, tag):
+    """Episode + full update at the shapes of BASELINE.json configs[1], [3], [4]: trajectory
+    teacher-forced to the oracle's (so a 1-ulp probability difference cannot fork it),
+    logits / values within 1e-5 of scale, every gradient within 1e-4 of its scale, and the
+    free-running sampled trajectory compared as well."""
+    from marlclassification_amd.engine import HipEngine
+    from tests.util import model_spec, uniform_params
+
+    cfg, na, nb, ns, shape = BIG_CASES[tag]
+    params = uniform_params(cfg, 7)
+    img = th.rand(nb, *shape, generator=th.Generator().manual_seed(11))
+    y = th.randint(0, cfg.nb_class, (nb,), generator=th.Generator().manual_seed(12))
+    inp = mo.draw_episode_inputs(cfg, na, nb, ns, shape[1:], 13)
+    th.set_num_threads(max(1, th.get_num_threads()))
+    tr, lo, grads = mo.train_iteration(params, cfg, img, y, inp, ns, 0.99)
+
+    eng = HipEngine(model_spec(cfg), device)
+    eng.configure(na, nb, ns, shape)
+    eng.pack({k: v.to(device) for k, v in params.items()})
+    args = [t.to(device) for t in (img, inp.pos0, inp.h0, inp.c0, inp.hc0, inp.cc0, inp.q)]
+    out = eng.episode_forward(*args, tr.step_actions.to(device), True)
+    assert th.equal(out.step_pos.cpu(), tr.step_pos)
+    errs = {"preds": _relerr(out.step_preds, tr.step_preds.detach()),
+            "logp": _relerr(out.step_log_probas, tr.step_log_probas.detach()),
+            "values": _relerr(out.step_values, tr.step_values.detach())}
+    assert max(errs.values()) <= ATOL, errs
+    gp, gl, gv, sc, st = eng.a2c_loss(out, y.to(device), 0.99)
+    assert abs(sc[0].item() - lo.loss.item()) <= 5e-5 * max(1.0, abs(lo.loss.item()))
+    g_out = {k: th.zeros_like(v, device=device) for k, v in params.items()}
+    eng.episode_backward(gp, gl, gv, g_out)
+    bad = {}
+    for k, ref in grads.items():
+        err = _maxerr(g_out[k], ref)
+        if not err <= 1e-4 * ref.abs().max().item() + 1e-7:
+            bad[k.replace("_ModelsWrapper__", "")] = "%.2e/%.2e" % (err, ref.abs().max().item())
+    assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
+    free = eng.episode_forward(*args, None, False)
+    nflip = (free.step_actions.cpu() != tr.step_actions).sum().item()
+    assert nflip <= max(1, tr.step_actions.numel() // 2000), f"{nflip} sampled actions differ"
