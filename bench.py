@@ -25,11 +25,22 @@ if ROOT not in sys.path:
 
 import torch as th  # noqa: E402
 
-# RESISC45 config of README.md:41 (column C3)
+# RESISC45 config of README.md:41 (column C3) - the headline workload
 C3 = dict(ft_extr="resisc45", window=12, n_b=256, n_a=256, n_m=64, n_m_o=96, n_d=16,
           nb_class=45, nlb=384, nla=384)
 NA, NS, IMG = 16, 16, (3, 256, 256)
 GAMMA, LR = 0.99, 1e-4
+# the other BASELINE.json configurations (--config; reported in DESIGN.md, not the bench line)
+OTHER = {
+    "c2": (dict(ft_extr="mnist", window=6, n_b=64, n_a=64, n_m=16, n_m_o=24, n_d=8, nb_class=10,
+                nlb=96, nla=96), 3, 5, (3, 28, 28), 1024, "MNIST 28x28, 3 agents, 5 steps, f=6"),
+    "c4": (dict(ft_extr="aid", window=24, n_b=256, n_a=256, n_m=64, n_m_o=96, n_d=16, nb_class=30,
+                nlb=320, nla=320, actions=[[3, 0], [-3, 0], [0, 3], [0, -3]]), 16, 16,
+           (3, 600, 600), 32, "AID 600x600, 16 agents, 16 steps, f=24"),
+    "c5": (dict(ft_extr="aid", window=32, n_b=256, n_a=256, n_m=64, n_m_o=96, n_d=16, nb_class=45,
+                nlb=384, nla=384, actions=[[4, 0], [-4, 0], [0, 4], [0, -4]]), 64, 32,
+           (3, 1024, 1024), 32, "synthetic 1024x1024, 64 agents, 32 steps, f=32"),
+}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 
@@ -88,7 +99,15 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-only", action="store_true")
+    ap.add_argument("--config", choices=["c3"] + sorted(OTHER), default="c3")
     args = ap.parse_args()
+    global C3, NA, NS, IMG
+    workload = "RESISC45 256x256x3, 16 agents, 16 steps, f=12, README dims (configs[2])"
+    if args.config != "c3":
+        C3, NA, NS, IMG, default_batch, workload = OTHER[args.config]
+        if args.batch == 256:
+            args.batch = default_batch
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,11 +136,13 @@ def main() -> None:
 
     lib = _lib.load()
     spec = ModelSpec(**C3)
+    is_c3 = args.config == "c3"
     eng = HipEngine(spec, dev)
     nb = args.batch
     eng.configure(NA, nb, NS, IMG)
     ocfg = OracleConfig(C3["ft_extr"], C3["window"], C3["n_b"], C3["n_a"], C3["n_m"], C3["n_m_o"],
-                        C3["n_d"], C3["nb_class"], C3["nlb"], C3["nla"])
+                        C3["n_d"], C3["nb_class"], C3["nlb"], C3["nla"],
+                        actions=C3.get("actions", [[1, 0], [-1, 0], [0, 1], [0, -1]]))
     flat = FlatParams(param_shapes(ocfg), dev)
     flat.load(init_params(ocfg, 0))  # reference init recipe (networks/init.py), same on all ranks
     hook = GradAllReduce(world) if distributed else None
@@ -171,7 +192,7 @@ def main() -> None:
         tot, cnt = C.c_double(0), C.c_int(0)
         lib.marl_profile_end(C.byref(tot), C.byref(cnt))
         avg_s = tot.value / max(1, cnt.value) / 1e3
-        achieved = lstm_flops_per_launch(NA * nb) / avg_s / 1e12
+        achieved = lstm_flops_per_launch(NA * nb) / avg_s / 1e12 if is_c3 else 0.0
         roofline = {
             "kernel": "gemm_nt_kernel<128,128,4,1,LSTM> (belief+action LSTM cells, fused epilogue)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -181,7 +202,7 @@ def main() -> None:
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE; profiles/r01_lstm_traffic.json says how they were taken)
         tpath = os.path.join(ROOT, "profiles", "r01_lstm_traffic.json")
-        if nb == 256 and os.path.exists(tpath):
+        if nb == 256 and is_c3 and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
                 roofline["traffic"] = json.load(f)["traffic_bytes_per_launch"]
             roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_lstm_traffic.json)"
@@ -200,8 +221,7 @@ def main() -> None:
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "RESISC45 256x256x3, 16 agents, 16 steps, f=12, README dims "
-                            "(configs[2]); full train iteration: rollout + A2C loss + BPTT "
+                "workload": workload + "; full train iteration: rollout + A2C loss + BPTT "
                             "backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
                 "batch_per_gpu": nb, "global_batch": nb * world,
                 "parallelism": f"dp{world}",
