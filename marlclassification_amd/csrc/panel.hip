@@ -17,15 +17,23 @@
 
 namespace marl {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float half_sum(float v) {  // over the 32 lanes of a half wave
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    return v;
+// Sum over the 64 lanes of a wave on the VALU (DPP row shifts + row broadcasts, then a
+// readlane of lane 63): no LDS-pipe ds_bpermute round trips, result is wave-uniform.
+__device__ __forceinline__ float wave_sum(float v) {
+    int x = __float_as_int(v);
+#define MARL_DPP_ADD(ctrl, rmask)                                                        \
+    x = __float_as_int(__int_as_float(x) +                                                \
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)))
+    MARL_DPP_ADD(0x111, 0xf);  // row_shr:1
+    MARL_DPP_ADD(0x112, 0xf);  // row_shr:2
+    MARL_DPP_ADD(0x114, 0xf);  // row_shr:4
+    MARL_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row's sum
+    MARL_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    MARL_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef MARL_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 // Workgroup barrier that only waits for LDS traffic: the global stores of saved activations
 // issued before it are never read back by this kernel, so there is no reason to drain vmcnt
@@ -38,101 +46,93 @@ __device__ __forceinline__ float silu_grad_p(float y) {
     const float s = 1.0f / (1.0f + expf(-y));
     return s * (1.0f + y * (1.0f - s));
 }
-__device__ __forceinline__ int tile_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-constexpr int kPanelRows = 32;
+// 16-row panels: R = Na*Nb = 4096 rows give 256 workgroups (one per CU); the f32 matrix-core
+// time of the widest layer (256 -> 384) is ~5 us per panel, half of what a 32-row panel on
+// half the CUs would need.
+constexpr int kPanelRows = 16;
 constexpr int kPanelMaxWaves = 12;  // 768 threads: 170 VGPRs per lane, no spills
+constexpr int kPanelMaxCols = 6;    // LayerNorm columns per lane: widths up to 384
 
-__host__ __device__ inline int panel_stride(int k) { return ((k + 7) & ~7) + 4; }
+__host__ __device__ inline int panel_stride(int k) { return ((k + 15) & ~15) + 4; }
 
-// One wave = one (column tile j, K slice s) pair: acc = in[32 x Kslice] (LDS) * W[tile rows,
-// Kslice]^T.  Weight fragments come straight from global memory (L2), 8 x 16-byte loads (a
-// 64-deep chunk) in flight per wave; splitting K over waves puts ALL of a layer's weight
-// loads in flight at once, so a layer costs ~one L2 round trip + <= 32 MFMAs per wave.
-__device__ __forceinline__ void panel_gemm(f32x16& acc, const float* in, int stride, int K,
+// One wave = one (32-column tile j, K slice s) pair, computed as two 16x16x4 MFMA sub-tiles:
+// acc[t] = in[16 x Kslice] (LDS) * W[16 tile rows, Kslice]^T.  Weight fragments come straight
+// from global memory (L2), 8 x 16-byte loads (a 64-deep chunk of both sub-tiles) in flight
+// per wave; splitting K over waves puts ALL of a layer's weight loads in flight at once.
+// C/D layout of the 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg.
+__device__ __forceinline__ void panel_gemm(f32x4 (&acc)[2], const float* in, int stride, int K,
                                            const float* __restrict__ w, int ldw, int n, int j,
                                            int kbeg, int kend, int lane) {
     const int K4 = (K + 3) & ~3;
-    const int half = lane >> 5;
-    const float* arow = in + (lane & 31) * stride + 4 * half;
-    int row = j * 32 + (lane & 31);
-    row = row < n ? row : n - 1;
-    const float* wrow = w + (size_t)row * ldw + 4 * half;
+    const int quad = lane >> 4, l16 = lane & 15;
+    const float* arow = in + l16 * stride + 4 * quad;
+    int r0 = j * 32 + l16, r1 = r0 + 16;
+    r0 = r0 < n ? r0 : n - 1;
+    r1 = r1 < n ? r1 : n - 1;
+    const float* w0 = w + (size_t)r0 * ldw + 4 * quad;
+    const float* w1 = w + (size_t)r1 * ldw + 4 * quad;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 4; ++r) acc[0][r] = acc[1][r] = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
-        float4 bq[8];
-        // columns [K, round8(K)) of the LDS panel are zero: a clamped (finite) read is exact
+        float4 b0[4], b1[4];
+        // columns [K, round16(K)) of the LDS panel are zero: a clamped (finite) read is exact
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kk = k0 + 8 * i;
-            bq[i] = *reinterpret_cast<const float4*>(wrow + (kk + 4 * half < K4 ? kk : -4 * half));
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k0 + 16 * i;
+            const int off = kk + 4 * quad < K4 ? kk : -4 * quad;
+            b0[i] = *reinterpret_cast<const float4*>(w0 + off);
+            b1[i] = *reinterpret_cast<const float4*>(w1 + off);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (k0 + 8 * i < kend) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 8 * i);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[i].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[i].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[i].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[i].w, acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            if (k0 + 16 * i < kend) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 16 * i);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[i].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[i].x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[i].y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[i].y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[i].z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[i].z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[i].w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[i].w, acc[1], 0, 0, 0);
             }
         }
     }
 }
 
-// K-slice partial tiles -> slice 0's accumulator (fixed order).  part: [(ks-1) * nt][64][16]
-__device__ __forceinline__ void panel_ksum(f32x16& acc, float* part, int nt, int ks, int j, int s,
+// K-slice partial tiles -> slice 0's accumulator (fixed order).  part: [(ks-1) * nt][64][8]
+__device__ __forceinline__ void panel_ksum(f32x4 (&acc)[2], float* part, int nt, int ks, int j, int s,
                                            int lane, bool active) {
     if (ks > 1) {
         if (active && s > 0) {
-            float* p = part + ((size_t)((s - 1) * nt + j) * 64 + lane) * 16;
-#pragma unroll
-            for (int r = 0; r < 16; r += 4)
-                *reinterpret_cast<float4*>(p + r) = make_float4(acc[r], acc[r + 1], acc[r + 2], acc[r + 3]);
+            float* p = part + ((size_t)((s - 1) * nt + j) * 64 + lane) * 8;
+            *reinterpret_cast<float4*>(p) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
         }
-        __syncthreads();
+        lds_barrier();
         if (active && s == 0) {
             for (int q = 1; q < ks; ++q) {
-                const float* p = part + ((size_t)((q - 1) * nt + j) * 64 + lane) * 16;
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(p + r);
-                    acc[r] += v.x;
-                    acc[r + 1] += v.y;
-                    acc[r + 2] += v.z;
-                    acc[r + 3] += v.w;
-                }
+                const float* p = part + ((size_t)((q - 1) * nt + j) * 64 + lane) * 8;
+                const float4 u = *reinterpret_cast<const float4*>(p);
+                const float4 v = *reinterpret_cast<const float4*>(p + 4);
+                acc[0][0] += u.x;
+                acc[0][1] += u.y;
+                acc[0][2] += u.z;
+                acc[0][3] += u.w;
+                acc[1][0] += v.x;
+                acc[1][1] += v.y;
+                acc[1][2] += v.z;
+                acc[1][3] += v.w;
             }
         }
     }
 }
 
-// Row sums over all columns of the panel: per-lane val[r] (this wave's tile, 0 if it has
-// none) -> res[32] * scale.  red: [nt][32] floats.
-__device__ __forceinline__ void panel_row_sum(const float (&val)[16], bool owner, int j, int nt,
-                                              float* red, float* res, int lane, float scale) {
-    const int half = lane >> 5;
-    if (owner) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float s = half_sum(val[r]);
-            if ((lane & 31) == 0) red[j * 32 + tile_row(r, half)] = s;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float s = 0.f;
-        for (int w = 0; w < nt; ++w) s += red[w * 32 + threadIdx.x];
-        res[threadIdx.x] = s * scale;
-    }
-    __syncthreads();
-}
-
 __host__ __device__ inline int panel_ksplit(int K, int nt, int nwaves) {
-    const int K8 = (K + 7) & ~7;
+    const int K16 = (K + 15) & ~15;
     int ks = nwaves / nt;
-    const int want = (K8 + 63) / 64;
+    const int want = (K16 + 63) / 64;
     ks = ks < want ? ks : want;
     return ks < 1 ? 1 : ks;
 }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(768) void panel_fwd_kernel(const PanelFwdBatch B) {
     const int m0 = blockIdx.x * kPanelRows;
     if (m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int half = lane >> 5;
+    const int quad = lane >> 4, l16 = lane & 15;
     float* X = lds;
     float* Y = lds + B.off_panel1;
     float* part = lds + B.off_part;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(768) void panel_fwd_kernel(const PanelFwdBatch B) {
 
     // ---- stage the 32-row input panel (zero-filled past k0 and past M)
     {
-        const int k0 = P.k0, xs = panel_stride(k0), K8 = (k0 + 7) & ~7;
-        const int c4 = K8 >> 2;
+        const int k0 = P.k0, xs = panel_stride(k0), K16 = (k0 + 15) & ~15;
+        const int c4 = K16 >> 2;
         const int K4 = (k0 + 3) & ~3;
         if (P.agg_na > 0) {
             // message mean over the OTHER agents (networks/message.py:5-17), 4 loads in flight
@@ -227,82 +227,87 @@ __global__ __launch_bounds__(768) void panel_fwd_kernel(const PanelFwdBatch B) {
         const float* in = (l & 1) ? Y : X;
         float* outp = (l & 1) ? X : Y;  // this layer's output panel (next layer's input)
         const int K = l == 0 ? P.k0 : P.layer[0].n;
-        const int K8 = (K + 7) & ~7;
+        const int K16 = (K + 15) & ~15;
         const int stride = panel_stride(K);
         const int n = Lr.n, nt = (n + 31) >> 5;
         const int ks = panel_ksplit(K, nt, nwaves);
         const int j = wave % nt, s = wave / nt;
         const bool active = s < ks;
-        const int kper = (((K8 + ks - 1) / ks) + 7) & ~7;
+        const int kper = (((K16 + ks - 1) / ks) + 15) & ~15;
         const int kbeg = s * kper;
-        const int kend = kbeg + kper < K8 ? kbeg + kper : K8;
-        f32x16 acc;
+        const int kend = kbeg + kper < K16 ? kbeg + kper : K16;
+        f32x4 acc[2];
         if (active) panel_gemm(acc, in, stride, K, Lr.w, Lr.ldw, n, j, kbeg, kend, lane);
         panel_ksum(acc, part, nt, ks, j, s, lane, active);
 
         // z = acc + bias -> output panel in LDS (and global, kept for backward)
-        const int ys = panel_stride(n), n8 = (n + 7) & ~7;
+        const int ys = panel_stride(n), n16 = (n + 15) & ~15;
         if (active && s == 0) {
-            const int col = j * 32 + (lane & 31);
-            const bool cv = col < n;
-            const float bv = cv ? lbias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = tile_row(r, half);
-                const float zv = cv ? acc[r] + bv : 0.f;
-                if (col < n8) outp[lr * ys + col] = zv;
-                if (cv && Lr.z && m0 + lr < P.m) Lr.z[(size_t)(m0 + lr) * Lr.ldz + col] = zv;
+            for (int t = 0; t < 2; ++t) {
+                const int col = j * 32 + 16 * t + l16;
+                const bool cv = col < n;
+                const float bv = cv ? lbias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = 4 * quad + r;
+                    const float zv = cv ? acc[t][r] + bv : 0.f;
+                    if (col < n16) outp[lr * ys + col] = zv;
+                    if (cv && Lr.z && m0 + lr < P.m) Lr.z[(size_t)(m0 + lr) * Lr.ldz + col] = zv;
+                }
             }
         }
         lds_barrier();
-        // LayerNorm + SiLU from the LDS panel: wave w owns rows w, w + nwaves, ... and walks
-        // them TOGETHER (independent shuffle chains interleave), two-pass statistics, result
-        // written in place (next layer's input) and to global.
+        // LayerNorm + SiLU: wave w owns rows w, w + nwaves, ...; a row lives in registers (<= 6
+        // columns per lane), two-pass statistics with VALU wave reductions, result written
+        // over the LDS panel (next layer's input) and to global.
         {
-            constexpr int RPW = 8;  // >= 32 rows / 4 waves
-            float sm[RPW], q[RPW], mean[RPW], rstd[RPW];
+            constexpr int RPW = 4;  // launcher guarantees >= 4 waves for the 16 rows
+            float g[kPanelMaxCols], bt[kPanelMaxCols];
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                sm[i] = 0.f;
-                const int lr = wave + i * nwaves;
-                if (lr < kPanelRows)
-                    for (int c = lane; c < n; c += 64) sm[i] += outp[lr * ys + c];
+            for (int u = 0; u < kPanelMaxCols; ++u) {
+                const int c = lane + 64 * u;
+                g[u] = c < n ? lgamma[c] : 0.f;
+                bt[u] = c < n ? lbeta[c] : 0.f;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) sm[i] += __shfl_xor(sm[i], o);
+            const float inv_n = 1.0f / (float)n;
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
-                mean[i] = sm[i] / (float)n;
-                q[i] = 0.f;
                 const int lr = wave + i * nwaves;
-                if (lr < kPanelRows)
-                    for (int c = lane; c < n; c += 64) {
-                        const float d = outp[lr * ys + c] - mean[i];
-                        q[i] += d * d;
-                    }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) q[i] += __shfl_xor(q[i], o);
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                rstd[i] = 1.0f / sqrtf(q[i] / (float)n + 1e-5f);
-                const int lr = wave + i * nwaves;
-                if (lr < kPanelRows) {
+                if (lr < kPanelRows) {  // wave-uniform
                     float* zr = outp + lr * ys;
+                    float v[kPanelMaxCols];
+                    float sm = 0.f;
+#pragma unroll
+                    for (int u = 0; u < kPanelMaxCols; ++u) {
+                        const int c = lane + 64 * u;
+                        v[u] = c < n ? zr[c] : 0.f;
+                        sm += v[u];
+                    }
+                    const float mean = wave_sum(sm) * inv_n;
+                    float q = 0.f;
+#pragma unroll
+                    for (int u = 0; u < kPanelMaxCols; ++u) {
+                        const int c = lane + 64 * u;
+                        const float d = c < n ? v[u] - mean : 0.f;
+                        v[u] = d;
+                        q += d * d;
+                    }
+                    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + 1e-5f);
                     const int row = m0 + lr;
                     float* arow = Lr.a + (size_t)row * Lr.lda;
-                    for (int c = lane; c < n; c += 64) {
-                        const float av = silu_p((zr[c] - mean[i]) * rstd[i] * lgamma[c] + lbeta[c]);
-                        zr[c] = av;
-                        if (row < P.m) arow[c] = av;
+#pragma unroll
+                    for (int u = 0; u < kPanelMaxCols; ++u) {
+                        const int c = lane + 64 * u;
+                        if (c < n) {
+                            const float av = silu_p(v[u] * rstd * g[u] + bt[u]);
+                            zr[c] = av;
+                            if (row < P.m) arow[c] = av;
+                        }
                     }
                     if (Lr.stats && lane == 0 && row < P.m) {
-                        Lr.stats[(size_t)row * 2] = mean[i];
-                        Lr.stats[(size_t)row * 2 + 1] = rstd[i];
+                        Lr.stats[(size_t)row * 2] = mean;
+                        Lr.stats[(size_t)row * 2 + 1] = rstd;
                     }
                 }
             }
@@ -315,7 +320,7 @@ constexpr size_t kPanelMaxLds = 144 * 1024;
 
 static int panel_waves_for(int k, int n) {
     const int nt = (n + 31) / 32;
-    const int want = (((k + 7) & ~7) + 63) / 64;
+    const int want = (((k + 15) & ~15) + 63) / 64;
     int w = nt * want;
     if (w < nt) w = nt;
     return w > kPanelMaxWaves ? (nt > kPanelMaxWaves ? -1 : (kPanelMaxWaves / nt) * nt) : w;
@@ -323,9 +328,10 @@ static int panel_waves_for(int k, int n) {
 
 int panel_supported(int k0, int n0, int n1) {
     if (n0 > 32 * kPanelMaxWaves || n1 > 32 * kPanelMaxWaves) return 0;  // one column tile per wave
+    if (n0 > 64 * kPanelMaxCols || n1 > 64 * kPanelMaxCols) return 0;
     const int kx = k0 > n1 ? k0 : n1;
     const size_t lds = (size_t)(kPanelRows * panel_stride(kx) + kPanelRows * panel_stride(n0) +
-                                (kPanelMaxWaves + 1) * 32 + (kPanelMaxWaves - 1) * 1024 +
+                                (kPanelMaxWaves + 1) * 32 + (kPanelMaxWaves - 1) * 512 +
                                 3 * (n0 + n1) + 16) * 4;
     return lds <= kPanelMaxLds;
 }
@@ -350,11 +356,11 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
         x0 = s0 > x0 ? s0 : x0;
         x1 = s1 > x1 ? s1 : x1;
     }
-    if (waves < 4) waves = 4;  // the LayerNorm row loop keeps <= 8 rows per wave in flight
+    if (waves < 4) waves = 4;  // the LayerNorm row loop covers <= 4 rows per wave
     b.off_panel1 = x0;
     b.off_red = x0 + x1;
     b.off_part = b.off_red + (kPanelMaxWaves + 1) * 32;
-    b.off_prm = b.off_part + (waves - 1) * 1024;
+    b.off_prm = b.off_part + (waves - 1) * 512;
     int prm = 0;
     for (int i = 0; i < b.count; ++i) {
         int q = 0;
@@ -383,14 +389,14 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
 // backward: d(SiLU out) -> [LayerNorm/SiLU backward on the LDS panel -> dz (kept) ->
 //           dX = dz * W on the matrix cores] per layer, last layer first
 // ===========================================================================
-constexpr int kBwdMaxCols = 6;  // columns per lane in the row pass: widths up to 384
+constexpr int kBwdMaxCols = kPanelMaxCols;  // columns per lane in the row pass: widths up to 384
 
 __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m0 = blockIdx.x * kPanelRows;
     if (m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int half = lane >> 5;
+    const int quad = lane >> 4, l16 = lane & 15;
     float* D = lds;            // current gradient panel
     float* E = lds + P.off_e;  // next one
     float* prm = lds + P.off_prm;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             }
             off += 2 * n;
         }
-        const int n = P.layer[0].n, ds = panel_stride(n), n8 = (n + 7) & ~7, c4 = n8 >> 2;
+        const int n = P.layer[0].n, ds = panel_stride(n), n16 = (n + 15) & ~15, c4 = n16 >> 2;
         const int n4 = (n + 3) & ~3;
         for (int e = tid; e < kPanelRows * c4; e += blockDim.x) {
             const int lr = e / c4, k = (e % c4) * 4;
@@ -423,69 +429,61 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
     int prm_off = 0;
     for (int l = 0; l < P.nlayers; ++l) {
         const PanelBwdLayer& Lr = P.layer[l];
-        const int n = Lr.n, ds = panel_stride(n), n8 = (n + 7) & ~7;
+        const int n = Lr.n, ds = panel_stride(n), n16 = (n + 15) & ~15;
         const float* lgamma = prm + prm_off;
         const float* lbeta = lgamma + n;
         prm_off += 2 * n;
-        // ---- row pass: D holds d(SiLU out); D <- dz, dgamma/dbeta column partials
+        // ---- row pass: D holds d(SiLU out); D <- dz, dgamma/dbeta column partials.  A row
+        // lives in registers between the statistics and the dz pass.
         {
-            constexpr int RPW = 4;  // launcher guarantees >= 8 waves
-            float pg[kBwdMaxCols], pb[kBwdMaxCols];
+            constexpr int RPW = 2;  // launcher guarantees >= 8 waves for the 16 rows
+            float pg[kBwdMaxCols], pb[kBwdMaxCols], g[kBwdMaxCols], bt[kBwdMaxCols];
 #pragma unroll
-            for (int u = 0; u < kBwdMaxCols; ++u) pg[u] = pb[u] = 0.f;
-            float s1[RPW], s2[RPW], mean[RPW], rstd[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                s1[i] = s2[i] = 0.f;
-                mean[i] = 0.f;
-                rstd[i] = 0.f;
-                const int lr = wave + i * nwaves;
-                const int row = m0 + lr;
-                if (lr < kPanelRows && row < P.m) {
-                    mean[i] = Lr.stats[(size_t)row * 2];
-                    rstd[i] = Lr.stats[(size_t)row * 2 + 1];
-                    const float* zr = Lr.z + (size_t)row * Lr.ldz;
-#pragma unroll
-                    for (int u = 0; u < kBwdMaxCols; ++u) {
-                        const int c = lane + 64 * u;
-                        if (c < n) {
-                            const float xh = (zr[c] - mean[i]) * rstd[i];
-                            const float g = lgamma[c];
-                            const float dy = D[lr * ds + c] * silu_grad_p(g * xh + lbeta[c]);
-                            const float dxh = dy * g;
-                            s1[i] += dxh;
-                            s2[i] += dxh * xh;
-                            pg[u] += dy * xh;
-                            pb[u] += dy;
-                        }
-                    }
-                }
+            for (int u = 0; u < kBwdMaxCols; ++u) {
+                const int c = lane + 64 * u;
+                pg[u] = pb[u] = 0.f;
+                g[u] = c < n ? lgamma[c] : 0.f;
+                bt[u] = c < n ? lbeta[c] : 0.f;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    s1[i] += __shfl_xor(s1[i], o);
-                    s2[i] += __shfl_xor(s2[i], o);
-                }
+            const float inv_n = 1.0f / (float)n;
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const int lr = wave + i * nwaves;
-                const int row = m0 + lr;
-                if (lr < kPanelRows) {
+                if (lr < kPanelRows) {  // wave-uniform
+                    const int row = m0 + lr;
                     const bool rv = row < P.m;
-                    const float m1 = s1[i] / (float)n, m2 = s2[i] / (float)n;
-                    const float* zr = Lr.z + (size_t)(rv ? row : 0) * Lr.ldz;
+                    float xh[kBwdMaxCols], dxh[kBwdMaxCols];
+                    float s1 = 0.f, s2 = 0.f, rstd = 0.f;
+                    if (rv) {
+                        const float mean = Lr.stats[(size_t)row * 2];
+                        rstd = Lr.stats[(size_t)row * 2 + 1];
+                        const float* zr = Lr.z + (size_t)row * Lr.ldz;
+#pragma unroll
+                        for (int u = 0; u < kBwdMaxCols; ++u) {
+                            const int c = lane + 64 * u;
+                            xh[u] = dxh[u] = 0.f;
+                            if (c < n) {
+                                xh[u] = (zr[c] - mean) * rstd;
+                                const float dy = D[lr * ds + c] * silu_grad_p(g[u] * xh[u] + bt[u]);
+                                dxh[u] = dy * g[u];
+                                s1 += dxh[u];
+                                s2 += dxh[u] * xh[u];
+                                pg[u] += dy * xh[u];
+                                pb[u] += dy;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < kBwdMaxCols; ++u) xh[u] = dxh[u] = 0.f;
+                    }
+                    const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
 #pragma unroll
                     for (int u = 0; u < kBwdMaxCols; ++u) {
                         const int c = lane + 64 * u;
-                        if (c < n8) {
+                        if (c < n16) {
                             float dzv = 0.f;
                             if (rv && c < n) {
-                                const float xh = (zr[c] - mean[i]) * rstd[i];
-                                const float g = lgamma[c];
-                                const float dxh = D[lr * ds + c] * silu_grad_p(g * xh + lbeta[c]) * g;
-                                dzv = rstd[i] * (dxh - m1 - xh * m2);
+                                dzv = rstd * (dxh[u] - m1 - xh[u] * m2);
                                 Lr.dz[(size_t)row * Lr.lddz + c] = dzv;
                             }
                             D[lr * ds + c] = dzv;
@@ -512,34 +510,37 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
         // ---- dX = dz * W: out tiles over k_in columns, contraction over n
         const int nout = Lr.k_in, nt = (nout + 31) >> 5;
         const int ks = panel_ksplit(n, nt, nwaves);
-        const int kper = (((n8 + ks - 1) / ks) + 7) & ~7;
+        const int kper = (((n16 + ks - 1) / ks) + 15) & ~15;
         const bool last = l + 1 == P.nlayers;
-        const int es = panel_stride(nout), o8 = (nout + 7) & ~7;
+        const int es = panel_stride(nout), o16 = (nout + 15) & ~15;
         // more column tiles than waves: walk them in rounds (first layer's input can be wide)
         for (int t0 = 0; t0 < nt; t0 += nwaves / ks) {
             const int tiles_round = nwaves / ks;
             const int j = t0 + wave % tiles_round, s = wave / tiles_round;
             const bool active = s < ks && j < nt;
             const int kbeg = s * kper;
-            const int kend = kbeg + kper < n8 ? kbeg + kper : n8;
-            f32x16 acc;
+            const int kend = kbeg + kper < n16 ? kbeg + kper : n16;
+            f32x4 acc[2];
             if (active) panel_gemm(acc, D, ds, n, Lr.wt, Lr.ldwt, nout, j, kbeg, kend, lane);
             // slice partials are indexed by the tile's slot in this round
             panel_ksum(acc, part, tiles_round, ks, wave % tiles_round, s, lane, active);
             if (active && s == 0) {
-                const int col = j * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = tile_row(r, half);
-                    const int row = m0 + lr;
-                    const float v = col < nout ? acc[r] : 0.f;
-                    if (last) {
-                        if (col < nout && row < P.m) {
-                            float* o = P.dx + (size_t)row * P.lddx + col;
-                            *o = P.accumulate ? *o + v : v;
+                for (int t = 0; t < 2; ++t) {
+                    const int col = j * 32 + 16 * t + l16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lr = 4 * quad + r;
+                        const int row = m0 + lr;
+                        const float v = col < nout ? acc[t][r] : 0.f;
+                        if (last) {
+                            if (col < nout && row < P.m) {
+                                float* o = P.dx + (size_t)row * P.lddx + col;
+                                *o = P.accumulate ? *o + v : v;
+                            }
+                        } else if (col < o16) {
+                            E[lr * es + col] = v;
                         }
-                    } else if (col < o8) {
-                        E[lr * es + col] = v;
                     }
                 }
             }
@@ -574,7 +575,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     p.off_prm = 2 * kPanelRows * pmax;
     p.off_colp = p.off_prm + prm + 16;
     p.off_part = p.off_colp + waves * 2 * nmax;
-    const size_t lds = (size_t)(p.off_part + (waves - 1) * 1024) * sizeof(float);
+    const size_t lds = (size_t)(p.off_part + (waves - 1) * 512) * sizeof(float);
     if (lds > kPanelMaxLds) {
         set_error("panel backward: shape outside its range");
         return MARL_ELIMIT;
