@@ -16,6 +16,24 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 void set_error(const char* fmt, ...);
 
+// Sum over the 64 lanes of a wave on the VALU (DPP row shifts + row broadcasts, then a
+// readlane of lane 63): no LDS-pipe ds_bpermute round trips, result is wave-uniform.
+// Call with all 64 lanes active.
+__device__ __forceinline__ float wave_sum(float v) {
+    int x = __float_as_int(v);
+#define MARL_DPP_ADD(ctrl, rmask)                         \
+    x = __float_as_int(__int_as_float(x) +                \
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)))
+    MARL_DPP_ADD(0x111, 0xf);  // row_shr:1
+    MARL_DPP_ADD(0x112, 0xf);  // row_shr:2
+    MARL_DPP_ADD(0x114, 0xf);  // row_shr:4
+    MARL_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row's sum
+    MARL_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    MARL_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef MARL_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 #define MARL_HIP_CHECK(expr)                                                        \
     do {                                                                            \
         hipError_t e_ = (expr);                                                     \
@@ -101,7 +119,7 @@ int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const
 int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, float* out, int n,
                            int accumulate, hipStream_t st);
 // LayerNorm/GroupNorm partials [nparts][2][n] -> dgamma[n], dbeta[n]
-int launch_reduce_affine(const float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
+int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
                          int accumulate, hipStream_t st);
 // out[n] = sum over rows of x[r][n]; scratch holds colsum_blocks(rows) * n floats
 int colsum_blocks(int64_t rows);

@@ -19,22 +19,6 @@ namespace marl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Sum over the 64 lanes of a wave on the VALU (DPP row shifts + row broadcasts, then a
-// readlane of lane 63): no LDS-pipe ds_bpermute round trips, result is wave-uniform.
-__device__ __forceinline__ float wave_sum(float v) {
-    int x = __float_as_int(v);
-#define MARL_DPP_ADD(ctrl, rmask)                                                        \
-    x = __float_as_int(__int_as_float(x) +                                                \
-                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)))
-    MARL_DPP_ADD(0x111, 0xf);  // row_shr:1
-    MARL_DPP_ADD(0x112, 0xf);  // row_shr:2
-    MARL_DPP_ADD(0x114, 0xf);  // row_shr:4
-    MARL_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row's sum
-    MARL_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-    MARL_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef MARL_DPP_ADD
-    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
-}
 // Workgroup barrier that only waits for LDS traffic: the global stores of saved activations
 // issued before it are never read back by this kernel, so there is no reason to drain vmcnt
 // (a plain __syncthreads() would wait for every outstanding store: ~1-2 us each time).

@@ -18,11 +18,6 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -201,25 +196,56 @@ int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, fl
     return MARL_OK;
 }
 
+// stage 1 of a long partial reduction: parts [y * chunk, (y + 1) * chunk) -> row y * chunk, in
+// place (each block only touches its own 64 columns of its own chunk; fixed order).
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(float* __restrict__ part, int64_t nparts,
+                                                            int64_t stride, int ncols, int chunk) {
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t p0 = (int64_t)blockIdx.y * chunk;
+    int64_t p1 = p0 + chunk;
+    if (p1 > nparts) p1 = nparts;
+    float s = 0.f;
+    if (c < ncols) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t p = p0 + grp;
+        for (; p + 12 < p1; p += 16) {
+            s0 += part[p * stride + c];
+            s1 += part[(p + 4) * stride + c];
+            s2 += part[(p + 8) * stride + c];
+            s3 += part[(p + 12) * stride + c];
+        }
+        for (; p < p1; p += 4) s0 += part[p * stride + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sh[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < ncols)
+        part[p0 * stride + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+
+// dgamma / dbeta (+)= sum over parts p * pstep, p < nparts, of part[..][2n]
 __global__ __launch_bounds__(256) void reduce_affine_kernel(const float* __restrict__ part,
-                                                            int64_t nparts, int n,
+                                                            int64_t nparts, int64_t pstep, int n,
                                                             float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta,
                                                             int accumulate) {
     __shared__ float sh[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;  // column in [0, 2n): gamma then beta
+    const int64_t rs = pstep * 2 * n;
     float s = 0.f;
     if (c < 2 * n) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int64_t p = grp;
         for (; p + 12 < nparts; p += 16) {
-            s0 += part[p * 2 * n + c];
-            s1 += part[(p + 4) * 2 * n + c];
-            s2 += part[(p + 8) * 2 * n + c];
-            s3 += part[(p + 12) * 2 * n + c];
+            s0 += part[p * rs + c];
+            s1 += part[(p + 4) * rs + c];
+            s2 += part[(p + 8) * rs + c];
+            s3 += part[(p + 12) * rs + c];
         }
-        for (; p < nparts; p += 4) s0 += part[p * 2 * n + c];
+        for (; p < nparts; p += 4) s0 += part[p * rs + c];
         s = (s0 + s1) + (s2 + s3);
     }
     sh[grp][lane] = s;
@@ -232,11 +258,23 @@ __global__ __launch_bounds__(256) void reduce_affine_kernel(const float* __restr
     }
 }
 
-int launch_reduce_affine(const float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
+// NOTE: long reductions (>= 256 parts) fold the partial buffer in place first - `part` is
+// consumed by this call.
+int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
                          int accumulate, hipStream_t st) {
     if (n <= 0) return MARL_OK;
+    int64_t pstep = 1;
+    if (nparts >= 256) {
+        int chunk = 16;
+        while ((int64_t)chunk * chunk < nparts) chunk <<= 1;  // ~sqrt split: 4096 -> 64 x 64
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)cdiv(2 * n, 64), (unsigned)cdiv(nparts, chunk)),
+                           dim3(256), 0, st, part, nparts, (int64_t)2 * n, 2 * n, chunk);
+        MARL_LAUNCH_CHECK();
+        pstep = chunk;
+        nparts = cdiv(nparts, chunk);
+    }
     hipLaunchKernelGGL(reduce_affine_kernel, dim3((unsigned)cdiv(2 * n, 64)), dim3(256), 0, st,
-                       part, nparts, n, dgamma, dbeta, accumulate);
+                       part, nparts, pstep, n, dgamma, dbeta, accumulate);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -796,14 +834,47 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
     float p[MARL_MAX_ACTIONS];
     float mx = -INFINITY;
 #pragma unroll
+    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) p[j] = 0.f;
+    // logits: the activation row lives in registers (8 columns per lane per pass), the output
+    // layer's rows are read four actions at a time so that all loads of a group are in flight
+    for (int base = 0; base < A.nla; base += 512) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = base + lane + 64 * u;
+            a[u] = k < A.nla ? ar[k] : 0.f;
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < MARL_MAX_ACTIONS; j0 += 4) {
+            if (j0 < A.nA) {
+                float wv[4][8];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = j0 + jj < A.nA ? j0 + jj : A.nA - 1;
+                    const float* wj = A.w1 + (size_t)j * A.ldw;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = base + lane + 64 * u;
+                        wv[jj][u] = k < A.nla ? wj[k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += a[u] * wv[jj][u];
+                    p[j0 + jj] += s;
+                }
+            }
+        }
+    }
+#pragma unroll
     for (int j = 0; j < MARL_MAX_ACTIONS; ++j) {
-        p[j] = 0.f;
         if (j < A.nA) {
-            const float* wj = A.w1 + (size_t)j * A.ldw;
-            float s = 0.f;
-            for (int k = lane; k < A.nla; k += 64) s += ar[k] * wj[k];
-            p[j] = wave_sum(s) + A.b1[j];
+            p[j] = wave_sum(p[j]) + A.b1[j];
             mx = fmaxf(mx, p[j]);
+        } else {
+            p[j] = 0.f;
         }
     }
     float den = 0.f;
@@ -838,16 +909,17 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
 #pragma unroll
     for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
         if (j == act) pa = p[j];
+    // every lane computes the move (wave-uniform), lane 0 stores it
+    const int pi0 = A.pos_in[r * 2], pi1 = A.pos_in[r * 2 + 1];
+    const int q0 = pi0 + A.table[act][0], q1 = pi1 + A.table[act][1];
+    const bool ok = q0 >= 0 && q0 + A.f < A.H && q1 >= 0 && q1 + A.f < A.W;
+    const int n0 = ok ? q0 : pi0, n1 = ok ? q1 : pi1;
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
             if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
         A.actions_i32[r] = act;
         A.step_logp[r] = logf(pa);
-        const int p0 = A.pos_in[r * 2], p1 = A.pos_in[r * 2 + 1];
-        const int q0 = p0 + A.table[act][0], q1 = p1 + A.table[act][1];
-        const bool ok = q0 >= 0 && q0 + A.f < A.H && q1 >= 0 && q1 + A.f < A.W;
-        const int n0 = ok ? q0 : p0, n1 = ok ? q1 : p1;
         A.pos_out[r * 2] = n0;
         A.pos_out[r * 2 + 1] = n1;
         if (A.step_pos) {
@@ -859,8 +931,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
     // position embedding of the NEXT step (networks/state.py:14-16 on pos / size), so that no
     // separate launch sits between the move and the next LSTM
     if (A.pe_W) {
-        const int n0 = __shfl(lane == 0 ? A.pos_out[r * 2] : 0, 0);
-        const int n1 = __shfl(lane == 0 ? A.pos_out[r * 2 + 1] : 0, 0);
         const float p0 = (float)n0 / (float)A.H, p1 = (float)n1 / (float)A.W;
         const int nd = A.pe_nd;
         if (lane == 0 && A.pe_npos) {

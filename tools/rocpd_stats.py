@@ -57,3 +57,28 @@ def gaps(path: str) -> None:
 
 if __name__ == "__main__" and len(sys.argv) > 1:
     gaps(sys.argv[1])
+
+
+def by_grid(path: str, pattern: str) -> None:
+    """per (kernel, grid, workgroup) breakdown for kernels whose name contains `pattern`"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else "kernel_name"
+    gcols = [c for c in ("grid_size_x", "grid_size_y", "grid_size_z", "workgroup_size_x", "grid_x",
+                         "grid_y", "grid_z", "workgroup_x") if c in cols]
+    rows = db.execute(f"select {namecol}, {', '.join(gcols)}, (end - start) from kernels").fetchall()
+    agg = {}
+    for r in rows:
+        if pattern not in r[0]:
+            continue
+        k = (short(r[0]),) + tuple(r[1:-1])
+        a = agg.setdefault(k, [0, 0])
+        a[0] += 1
+        a[1] += r[-1]
+    print("# by grid:", gcols)
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{k} calls {a[0]} total_ms {a[1] / 1e6:.3f} avg_us {a[1] / a[0] / 1e3:.2f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 3:
+    by_grid(sys.argv[1], sys.argv[3])
