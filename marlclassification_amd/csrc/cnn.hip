@@ -96,6 +96,258 @@ int launch_obs_im2col(const float* obs, float* cols, int ldk, int64_t rows, int 
     return MARL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Fused CNN forward for one step (networks/vision.py:13-53 applied to the patches of
+// core/environment.py:95-126).  One workgroup owns `rb` patches end to end:
+//   layer-0 im2col tile straight from the image (LDS) -> for every layer:
+//   [tile -> global (kept for the weight gradients)] -> conv as 16x16x4 f32 MFMA tiles, weights
+//   streamed from L2 -> + bias -> Z (LDS + global) -> GroupNorm statistics (wave per
+//   (patch, group)) -> normalise + SiLU while gathering the NEXT layer's im2col tile in LDS
+//   (or the flattened feature row of U after the last layer).
+// Replaces gather + L x (GEMM launch + GroupNorm/im2col launch): the intermediates never
+// leave the CU, the only HBM traffic is the buffers backward needs.
+// ---------------------------------------------------------------------------
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float cnn_silu(float y) { return y / (1.0f + expf(-y)); }
+
+__global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* T = lds;               // im2col tile of the current layer [rows16 + 1][s]
+    float* Zb = lds + A.off_z;    // conv output [rb * P][cout + 4]
+    float* gstat = lds + A.off_stat;  // [rb * G][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int quad = lane >> 4, l16 = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * A.rb;
+    const int nrow = (int)(A.rows - row0 < A.rb ? A.rows - row0 : A.rb);
+
+    // ---- layer-0 im2col tile from the image (zero padding taps, zero tail rows)
+    {
+        const CnnFwdLayer& L0 = A.layer[0];
+        const int s0 = A.s[0], P = L0.P, cin = L0.cin, K = L0.K, hout = L0.hout, f = A.f;
+        const int M = nrow * P;
+        const int tot = (((M + 15) & ~15) + 1) * s0;
+        const float* imgf = static_cast<const float*>(A.img);
+        const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+#pragma unroll 4
+        for (int idx = tid; idx < tot; idx += nthreads) {
+            const int mo = idx / s0, k = idx - mo * s0;
+            float v = 0.f;
+            if (mo < M && k < K) {
+                const int lr = mo / P, opos = mo - lr * P;
+                const int tap = k / cin, ci = k - tap * cin;
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const int oy = opos / hout, ox = opos - oy * hout;
+                const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
+                if (iy >= 0 && iy < f && ix >= 0 && ix < f) {
+                    const int64_t r = row0 + lr;
+                    if (A.obs) {
+                        v = A.obs[((r * A.c_img + ci) * f + iy) * f + ix];
+                    } else {
+                        const int b = (int)(r % A.nb);
+                        const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
+                        const int64_t off = (((int64_t)b * A.c_img + ci) * A.H + (p0 + iy)) * A.W + (p1 + ix);
+                        v = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];  // ToTensor on the fly
+                    }
+                }
+            }
+            T[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < A.L; ++l) {
+        const CnnFwdLayer& Ly = A.layer[l];
+        const int s = A.s[l], P = Ly.P, cout = Ly.cout, K = Ly.K, ldk = Ly.ldk;
+        const int M = nrow * P, MT = (M + 15) >> 4, NT = (cout + 15) >> 4;
+        const int zs = cout + 4;
+        // ---- this layer's im2col rows -> global (the weight-gradient GEMM reads them)
+        if (Ly.cols) {
+            const int c4 = ldk >> 2;
+            float* dst = Ly.cols + row0 * P * (int64_t)ldk;
+            for (int idx = tid; idx < M * c4; idx += nthreads) {
+                const int m = idx / c4, k = (idx - m * c4) * 4;
+                *reinterpret_cast<float4*>(dst + (int64_t)m * ldk + k) =
+                    *reinterpret_cast<const float4*>(T + m * s + k);
+            }
+        }
+        // ---- conv: Z[m][n] = sum_k T[m][k] * W[n][k] + bias[n]; one 16x16 tile per wave turn
+        const int steps = (K + 15) >> 4;
+        for (int ti = wave; ti < MT * NT; ti += nwaves) {
+            const int nt = ti % NT, mt = ti / NT;
+            const float* arow = T + (mt * 16 + l16) * s + 4 * quad;
+            int wr = nt * 16 + l16;
+            wr = wr < cout ? wr : cout - 1;
+            const float* wrow = Ly.w + (int64_t)wr * ldk + 4 * quad;
+            cf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int st0 = 0; st0 < steps; st0 += 8) {
+                float4 bq[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = (st0 + i) * 16;
+                    const bool ok = st0 + i < steps && kk + 4 * quad < ldk;
+                    const float4 v = *reinterpret_cast<const float4*>(wrow + (ok ? kk : -4 * quad));
+                    bq[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (st0 + i < steps) {
+                        const float4 a = *reinterpret_cast<const float4*>(arow + (st0 + i) * 16);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[i].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[i].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[i].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[i].w, acc, 0, 0, 0);
+                    }
+                }
+            }
+            const int n = nt * 16 + l16;
+            if (n < cout) {
+                const float bv = Ly.bias[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * quad + r;
+                    if (m < M) {
+                        const float zv = acc[r] + bv;
+                        Zb[m * zs + n] = zv;
+                        if (Ly.z) Ly.z[(row0 * P + m) * (int64_t)cout + n] = zv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- GroupNorm statistics (eps 1e-5, biased variance, two passes): wave per (patch, group)
+        const int G = Ly.G, cpg = cout / G, cnt = P * cpg;
+        for (int pi = wave; pi < nrow * G; pi += nwaves) {
+            const int lr = pi / G, g = pi - lr * G;
+            const float* base = Zb + lr * P * zs + g * cpg;
+            float sm = 0.f;
+            for (int e = lane; e < cnt; e += 64) {
+                const int pos = e / cpg;
+                sm += base[pos * zs + (e - pos * cpg)];
+            }
+            const float mean = wave_sum(sm) / (float)cnt;
+            float q = 0.f;
+            for (int e = lane; e < cnt; e += 64) {
+                const int pos = e / cpg;
+                const float d = base[pos * zs + (e - pos * cpg)] - mean;
+                q += d * d;
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+            if (lane == 0) {
+                gstat[pi * 2] = mean;
+                gstat[pi * 2 + 1] = rstd;
+                if (Ly.gst) {
+                    Ly.gst[((row0 + lr) * G + g) * 2] = mean;
+                    Ly.gst[((row0 + lr) * G + g) * 2 + 1] = rstd;
+                }
+            }
+        }
+        __syncthreads();
+        if (l + 1 < A.L) {
+            // ---- normalise + SiLU while gathering the next layer's im2col tile (3x3, stride 2,
+            // pad 1; k = tap * cin + ci, float4 along ci)
+            const CnnFwdLayer& Nx = A.layer[l + 1];
+            const int s1 = A.s[l + 1], c4 = s1 >> 2, P1 = Nx.P, hin = Ly.hout, hout = Nx.hout;
+            const int M1 = nrow * P1;
+            const int tot = (((M1 + 15) & ~15) + 1) * c4;
+            for (int idx = tid; idx < tot; idx += nthreads) {
+                const int mo = idx / c4, k = (idx - mo * c4) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mo < M1 && k < Nx.K) {
+                    const int lr = mo / P1, opos = mo - lr * P1;
+                    const int tap = k / cout, ci = k - tap * cout;
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const int oy = opos / hout, ox = opos - oy * hout;
+                    const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
+                    if (iy >= 0 && iy < hin && ix >= 0 && ix < hin) {
+                        const float4 z = *reinterpret_cast<const float4*>(Zb + (lr * P + iy * hin + ix) * zs + ci);
+                        const int g = ci / cpg;
+                        const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+                        const float4 gm = *reinterpret_cast<const float4*>(Ly.gamma + ci);
+                        const float4 bt = *reinterpret_cast<const float4*>(Ly.beta + ci);
+                        v.x = cnn_silu((z.x - mean) * rstd * gm.x + bt.x);
+                        v.y = cnn_silu((z.y - mean) * rstd * gm.y + bt.y);
+                        v.z = cnn_silu((z.z - mean) * rstd * gm.z + bt.z);
+                        v.w = cnn_silu((z.w - mean) * rstd * gm.w + bt.w);
+                    }
+                }
+                *reinterpret_cast<float4*>(T + mo * s1 + k) = v;
+            }
+        } else {
+            // ---- last layer: features in the reference's (C, H, W) flatten order -> U
+            const int E = P * cout;
+            for (int idx = tid; idx < nrow * E; idx += nthreads) {
+                const int lr = idx / E, e = idx - lr * E;
+                const int c = e / P, pos = e - c * P;
+                const int g = c / cpg;
+                const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+                const float zv = Zb[(lr * P + pos) * zs + c];
+                A.u[(row0 + lr) * (int64_t)A.ldu + e] = cnn_silu((zv - mean) * rstd * Ly.gamma[c] + Ly.beta[c]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int cnn_lds_stride(int ldk) { return (ldk & 7) == 4 ? ldk : ldk + 4; }
+
+// LDS floats for rb patches per workgroup; fills a.s / a.off_*
+static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
+    size_t tile = 0, zb = 0, st = 0;
+    for (int l = 0; l < a.L; ++l) {
+        const CnnFwdLayer& L = a.layer[l];
+        a.s[l] = cnn_lds_stride(L.ldk);
+        const size_t rows16 = (((size_t)rb * L.P + 15) & ~(size_t)15) + 1;
+        // + 16 floats: the last k-step of the last row may read past the row stride
+        const size_t t = rows16 * a.s[l] + 16;
+        tile = t > tile ? t : tile;
+        const size_t z = (size_t)rb * L.P * (L.cout + 4);
+        zb = z > zb ? z : zb;
+        const size_t g = (size_t)rb * L.G * 2;
+        st = g > st ? g : st;
+    }
+    tile = (tile + 3) & ~(size_t)3;
+    zb = (zb + 3) & ~(size_t)3;
+    a.rb = rb;
+    a.off_z = (int)tile;
+    a.off_stat = (int)(tile + zb);
+    return tile + zb + st;
+}
+
+int cnn_fwd_supported(const CnnFwdArgs& a0) {
+    if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
+    CnnFwdArgs a = a0;
+    for (int l = 0; l < a.L; ++l) {
+        const CnnFwdLayer& L = a.layer[l];
+        if (L.cout % L.G != 0 || ((L.cout / L.G) & 3) || (L.cout & 3)) return 0;  // float4 stays inside a group
+        if (l > 0 && (L.cin & 3)) return 0;
+    }
+    return cnn_fwd_plan(a, 1) * sizeof(float) <= 144 * 1024;
+}
+
+int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
+    if (a.rows <= 0) return MARL_OK;
+    // as many patches per workgroup as fit two workgroups per CU (the conv weights are re-read
+    // from L2 by every workgroup), but keep >= 256 workgroups
+    int rb = 8;
+    while (rb > 1 && (cnn_fwd_plan(a, rb) * sizeof(float) > 72 * 1024 || cdiv(a.rows, rb) < 256)) --rb;
+    const size_t lds = cnn_fwd_plan(a, rb) * sizeof(float);
+    if (lds > 144 * 1024) {
+        set_error("fused CNN forward: window %d outside its range", a.f);
+        return MARL_ELIMIT;
+    }
+    static bool raised = false;
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL(cnn_fwd_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
 // Environment.observe(): obs[r, c, y, x] = img[b, c, p0 + y, p1 + x]
 __global__ void patch_gather_kernel(const float* __restrict__ img, const int64_t* __restrict__ pos,
                                     float* __restrict__ obs, int64_t rows, int nb, int c, int H,

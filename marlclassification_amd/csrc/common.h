@@ -288,6 +288,34 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
 // ---------------------------------------------------------------------------
 // Patch gather fused with the first layer's im2col: img [Nb,Cimg,H,W], pos int32 [R,2]
 // -> cols [R * P, ldk], k = (kh*3+kw)*cin + ci, P = oh*ow, oh = (f-1)/2+1.
+// ---------------------------------------------------------------------------
+// Fused per-step CNN forward (cnn.hip): gather + [im2col -> conv -> GroupNorm -> SiLU] x L
+// ---------------------------------------------------------------------------
+struct CnnFwdLayer {
+    const float *w, *bias, *gamma, *beta;  // packed conv weight [cout][ldk] (k = tap * cin + ci)
+    float* cols;                           // [R * P][ldk] im2col rows kept for backward (or null)
+    float* z;                              // [R * P][cout] conv output kept for backward (or null)
+    float* gst;                            // [R][G][2] mean / rstd (or null)
+    int cin, cout, G, hin, hout, P, K, ldk;
+};
+struct CnnFwdArgs {
+    const void* img;     // [Nb][c_img][H][W] float or uint8
+    const float* obs;    // standalone step API: [R][c_img][f][f] patches (img unused)
+    const int32_t* pos;  // [R][2]
+    int img_u8;
+    int64_t rows;
+    int nb, c_img, H, W, f, L;
+    CnnFwdLayer layer[MARL_MAX_CNN_LAYERS];
+    float* u;  // [R][ldu], feature index c * P_last + pos (the reference's NCHW flatten)
+    int ldu;
+    // filled by the launcher
+    int rb;                         // patches per workgroup
+    int s[MARL_MAX_CNN_LAYERS];     // LDS row stride of layer l's im2col tile
+    int off_z, off_stat;            // LDS float offsets
+};
+int cnn_fwd_supported(const CnnFwdArgs& a);
+int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st);
+
 int launch_gather_im2col(const void* img, int img_u8, const int32_t* pos, float* cols, int ldk,
                          int na, int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
 // same but from pre-gathered patches obs [R, c_img, f, f] (standalone step API)

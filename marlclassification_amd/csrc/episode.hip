@@ -469,6 +469,32 @@ static bool use_panels(const Dims& d) {
 static int step_cnn(const Ctx& c, int t, const StepIn& in) {
     const Dims& d = c.d;
     hipStream_t st = c.st;
+    {
+        // one fused launch for the whole extractor when the shapes allow it
+        const bool keep = c.train != 0;
+        CnnFwdArgs a{};
+        a.img = in.img;
+        a.obs = in.obs;
+        a.pos = c.POSs(t);
+        a.img_u8 = in.img_u8;
+        a.rows = d.R;
+        a.nb = d.nb;
+        a.c_img = d.c_img;
+        a.H = d.H;
+        a.W = d.W;
+        a.f = d.f;
+        a.L = d.L;
+        for (int l = 0; l < d.L; ++l)
+            a.layer[l] = CnnFwdLayer{c.wp(4 * l), c.wp(4 * l + 1), c.wp(4 * l + 2), c.wp(4 * l + 3),
+                                     keep ? c.at(c.e.COLS[l], t) : nullptr,
+                                     keep ? c.at(c.e.Z[l], t) : nullptr,
+                                     keep ? c.at(c.e.GST[l], t) : nullptr,
+                                     d.ch[l], d.ch[l + 1], d.grp[l], d.hw[l], d.hw[l + 1], d.P[l],
+                                     d.K[l], d.ldk[l]};
+        a.u = c.at(c.e.U, t);
+        a.ldu = d.ld_nin;
+        if (cnn_fwd_supported(a)) return launch_cnn_fwd(a, st);
+    }
     if (in.obs)
         MARL_TRY(launch_obs_im2col(in.obs, c.at(c.e.COLS[0], t), d.ldk[0], d.R, d.c_img, d.ch[0],
                                    d.f, st));
