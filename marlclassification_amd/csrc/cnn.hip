@@ -4,6 +4,8 @@
 // (networks/vision.py:33-35).  Convolutions themselves run on the matrix cores as
 // cols[rows*P, 9*Cin] x W[Cout, 9*Cin]^T (gemm.hip).  K order is (kh, kw, ci) so that
 // NHWC activations give 16-byte contiguous chunks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace marl {
@@ -99,84 +101,119 @@ int launch_obs_im2col(const float* obs, float* cols, int ldk, int64_t rows, int 
 // ---------------------------------------------------------------------------
 // Fused CNN forward for one step (networks/vision.py:13-53 applied to the patches of
 // core/environment.py:95-126).  One workgroup owns `rb` patches end to end:
-//   layer-0 im2col tile straight from the image (LDS) -> for every layer:
-//   [tile -> global (kept for the weight gradients)] -> conv as 16x16x4 f32 MFMA tiles, weights
-//   streamed from L2 -> + bias -> Z (LDS + global) -> GroupNorm statistics (wave per
-//   (patch, group)) -> normalise + SiLU while gathering the NEXT layer's im2col tile in LDS
-//   (or the flattened feature row of U after the last layer).
+//   raw patches -> LDS; for every layer: conv as 16x16x4 f32 MFMA tiles whose A fragments are
+//   gathered straight from the previous activation in LDS (implicit im2col: 3x3, stride 2,
+//   pad 1, k = tap * cin + ci) and whose weights stream from L2; the gathered fragments are
+//   also the im2col rows backward needs, so they go to global from registers -> + bias -> Z
+//   (LDS + global) -> GroupNorm statistics (wave per (patch, group)) -> normalise + SiLU in
+//   place (the next layer's input), or the flattened feature row of U after the last layer.
 // Replaces gather + L x (GEMM launch + GroupNorm/im2col launch): the intermediates never
 // leave the CU, the only HBM traffic is the buffers backward needs.
 // ---------------------------------------------------------------------------
+#ifdef MARL_KERNEL_TS
+int ts_begin(long long** dev, int call) {
+    if (!*dev) (void)hipMalloc(dev, 16 * 48 * sizeof(long long));
+    const char* e = getenv("MARL_TS_CALL");
+    const int want = e ? atoi(e) : 100;
+    if (call != want) return 0;
+    (void)hipMemset(*dev, 0, 16 * 48 * sizeof(long long));
+    return 1;
+}
+void ts_report(const char* tag, long long* dev, int waves) {
+    static long long h[16 * 48];
+    (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+    for (int w = 0; w < waves; w += (waves > 1 ? waves - 1 : 1)) {
+        const long long* t = h + w * 48;
+        fprintf(stderr, "[ts] %s wave %d/%d:", tag, w, waves);
+        long long tot = 0;
+        for (int i = 1; i < 48 && t[i]; ++i) {
+            fprintf(stderr, " %lld", t[i] - t[i - 1]);
+            tot += t[i] - t[i - 1];
+        }
+        fprintf(stderr, " | total %.2f us\n", tot / 100.0);
+    }
+}
+#endif
+
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float cnn_silu(float y) { return y / (1.0f + expf(-y)); }
 
 __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* T = lds;               // im2col tile of the current layer [rows16 + 1][s]
-    float* Zb = lds + A.off_z;    // conv output [rb * P][cout + 4]
-    float* gstat = lds + A.off_stat;  // [rb * G][2]
+    float* patch = lds;                  // [rb][cin0][f][f]
+    float* gstat = lds + A.off_stat;     // [rb * G][2]
+    __shared__ int64_t simg[16];         // per patch: offset of its image (or observation)
+    __shared__ int spos[16][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int quad = lane >> 4, l16 = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * A.rb;
     const int nrow = (int)(A.rows - row0 < A.rb ? A.rows - row0 : A.rb);
 
-    // ---- layer-0 im2col tile from the image (zero padding taps, zero tail rows)
-    {
-        const CnnFwdLayer& L0 = A.layer[0];
-        const int s0 = A.s[0], P = L0.P, cin = L0.cin, K = L0.K, hout = L0.hout, f = A.f;
-        const int M = nrow * P;
-        const int tot = (((M + 15) & ~15) + 1) * s0;
-        const float* imgf = static_cast<const float*>(A.img);
-        const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
-#pragma unroll 4
-        for (int idx = tid; idx < tot; idx += nthreads) {
-            const int mo = idx / s0, k = idx - mo * s0;
-            float v = 0.f;
-            if (mo < M && k < K) {
-                const int lr = mo / P, opos = mo - lr * P;
-                const int tap = k / cin, ci = k - tap * cin;
-                const int kh = tap / 3, kw = tap - 3 * kh;
-                const int oy = opos / hout, ox = opos - oy * hout;
-                const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
-                if (iy >= 0 && iy < f && ix >= 0 && ix < f) {
-                    const int64_t r = row0 + lr;
-                    if (A.obs) {
-                        v = A.obs[((r * A.c_img + ci) * f + iy) * f + ix];
-                    } else {
-                        const int b = (int)(r % A.nb);
-                        const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
-                        const int64_t off = (((int64_t)b * A.c_img + ci) * A.H + (p0 + iy)) * A.W + (p1 + ix);
-                        v = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];  // ToTensor on the fly
-                    }
-                }
-            }
-            T[idx] = v;
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(A.ts);
+#endif
+    MARL_TS();
+    if (tid < nrow) {
+        const int64_t r = row0 + tid;
+        if (A.obs) {
+            simg[tid] = r * A.c_img * A.f * A.f;
+            spos[tid][0] = spos[tid][1] = 0;
+        } else {
+            simg[tid] = (r % A.nb) * A.c_img * (int64_t)A.H * A.W;
+            spos[tid][0] = A.pos[r * 2];
+            spos[tid][1] = A.pos[r * 2 + 1];
         }
     }
     __syncthreads();
+    // ---- raw patches -> LDS
+    {
+        const int f = A.f, ff = f * f, pe = A.layer[0].cin * ff;
+        const float* imgf = static_cast<const float*>(A.img);
+        const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+#pragma unroll 4
+        for (int idx = tid; idx < nrow * pe; idx += nthreads) {
+            const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
+            float v;
+            if (A.obs) {
+                v = A.obs[simg[lr] + e];
+            } else {
+                const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
+                const int iy = fdiv(e2, A.df), ix = e2 - iy * f;
+                const int64_t off = simg[lr] + ((int64_t)ci * A.H + (spos[lr][0] + iy)) * A.W + (spos[lr][1] + ix);
+                v = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];  // ToTensor on the fly
+            }
+            patch[idx] = v;
+        }
+    }
+    MARL_TS();
+    __syncthreads();
+    MARL_TS();
 
     for (int l = 0; l < A.L; ++l) {
         const CnnFwdLayer& Ly = A.layer[l];
-        const int s = A.s[l], P = Ly.P, cout = Ly.cout, K = Ly.K, ldk = Ly.ldk;
+        const int P = Ly.P, cin = Ly.cin, cout = Ly.cout, K = Ly.K, ldk = Ly.ldk, hin = Ly.hin,
+                  hout = Ly.hout;
         const int M = nrow * P, MT = (M + 15) >> 4, NT = (cout + 15) >> 4;
         const int zs = cout + 4;
-        // ---- this layer's im2col rows -> global (the weight-gradient GEMM reads them)
-        if (Ly.cols) {
-            const int c4 = ldk >> 2;
-            float* dst = Ly.cols + row0 * P * (int64_t)ldk;
-            for (int idx = tid; idx < M * c4; idx += nthreads) {
-                const int m = idx / c4, k = (idx - m * c4) * 4;
-                *reinterpret_cast<float4*>(dst + (int64_t)m * ldk + k) =
-                    *reinterpret_cast<const float4*>(T + m * s + k);
-            }
-        }
-        // ---- conv: Z[m][n] = sum_k T[m][k] * W[n][k] + bias[n]; one 16x16 tile per wave turn
+        const float* in = l == 0 ? patch : lds + ((l & 1) ? A.off_b0 : A.off_b1);
+        float* Zb = lds + ((l & 1) ? A.off_b1 : A.off_b0);
+        const bool vec = l > 0;            // cin % 4 == 0: a fragment is one float4 along ci
+        const int cs = cin + 4;            // channel stride of the NHWC input (l > 0)
+        const int in_per = l == 0 ? cin * hin * hin : hin * hin * cs;
+        // ---- conv: Z[m][n] = sum_k im2col(in)[m][k] * W[n][k] + bias[n]; a 16x16 tile per turn
         const int steps = (K + 15) >> 4;
         for (int ti = wave; ti < MT * NT; ti += nwaves) {
-            const int nt = ti % NT, mt = ti / NT;
-            const float* arow = T + (mt * 16 + l16) * s + 4 * quad;
+            const int mt = fdiv(ti, A.dNT[l]), nt = ti - mt * NT;
+            const int m = mt * 16 + l16;
+            const bool mv = m < M;
+            const int lr = fdiv(m, A.dP[l]), opos = m - lr * P;
+            const int oy = fdiv(opos, A.dhout[l]), ox = opos - oy * hout;
+            const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+            const float* src = in + lr * in_per;
+            const bool wcols = Ly.cols != nullptr && nt == 0;
+            float* crow = Ly.cols + (row0 * P + m) * (int64_t)ldk;
             int wr = nt * 16 + l16;
             wr = wr < cout ? wr : cout - 1;
             const float* wrow = Ly.w + (int64_t)wr * ldk + 4 * quad;
@@ -193,7 +230,33 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (st0 + i < steps) {
-                        const float4 a = *reinterpret_cast<const float4*>(arow + (st0 + i) * 16);
+                        const int k = (st0 + i) * 16 + 4 * quad;
+                        float4 a;
+                        if (vec) {
+                            const int tap = fdiv(k, A.dcin[l]), ci = k - tap * cin;
+                            const int kh = tap / 3, kw = tap - 3 * kh;
+                            const int iy = iy0 + kh, ix = ix0 + kw;
+                            const bool ok = mv && k < K && (unsigned)iy < (unsigned)hin &&
+                                            (unsigned)ix < (unsigned)hin;
+                            a = *reinterpret_cast<const float4*>(src + (ok ? (iy * hin + ix) * cs + ci : 0));
+                            if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            float av[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int kj = k + j;
+                                const int tap = fdiv(kj, A.dcin[l]), ci = kj - tap * cin;
+                                const int kh = tap / 3, kw = tap - 3 * kh;
+                                const int iy = iy0 + kh, ix = ix0 + kw;
+                                const bool ok = mv && kj < K && (unsigned)iy < (unsigned)hin &&
+                                                (unsigned)ix < (unsigned)hin;
+                                const float t = src[ok ? (ci * hin + iy) * hin + ix : 0];
+                                av[j] = ok ? t : 0.f;
+                            }
+                            a = make_float4(av[0], av[1], av[2], av[3]);
+                        }
+                        // the im2col row kept for the weight-gradient GEMM
+                        if (wcols && mv && k < ldk) *reinterpret_cast<float4*>(crow + k) = a;
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[i].x, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[i].y, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[i].z, acc, 0, 0, 0);
@@ -206,113 +269,134 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
                 const float bv = Ly.bias[n];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = mt * 16 + 4 * quad + r;
-                    if (m < M) {
+                    const int mr = mt * 16 + 4 * quad + r;
+                    if (mr < M) {
                         const float zv = acc[r] + bv;
-                        Zb[m * zs + n] = zv;
-                        if (Ly.z) Ly.z[(row0 * P + m) * (int64_t)cout + n] = zv;
+                        Zb[mr * zs + n] = zv;
+                        if (Ly.z) Ly.z[(row0 * P + mr) * (int64_t)cout + n] = zv;
                     }
                 }
             }
         }
+        MARL_TS();
         __syncthreads();
-        // ---- GroupNorm statistics (eps 1e-5, biased variance, two passes): wave per (patch, group)
-        const int G = Ly.G, cpg = cout / G, cnt = P * cpg;
-        for (int pi = wave; pi < nrow * G; pi += nwaves) {
-            const int lr = pi / G, g = pi - lr * G;
-            const float* base = Zb + lr * P * zs + g * cpg;
-            float sm = 0.f;
-            for (int e = lane; e < cnt; e += 64) {
-                const int pos = e / cpg;
-                sm += base[pos * zs + (e - pos * cpg)];
+        MARL_TS();
+        // ---- GroupNorm statistics (eps 1e-5, biased variance, two passes): wave per (patch,
+        // group), four pairs walked together so their reduction chains overlap
+        const int G = Ly.G, cpg = (int)A.dcpg[l].d, cnt = P * cpg, npairs = nrow * G;
+        for (int pi0 = wave * 4; pi0 < npairs; pi0 += nwaves * 4) {
+            const float* base[4];
+            float sm[4], q[4], mean[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pi = pi0 + u < npairs ? pi0 + u : npairs - 1;
+                const int lr = fdiv(pi, A.dG[l]), g = pi - lr * G;
+                base[u] = Zb + lr * P * zs + g * cpg;
+                sm[u] = q[u] = 0.f;
             }
-            const float mean = wave_sum(sm) / (float)cnt;
-            float q = 0.f;
             for (int e = lane; e < cnt; e += 64) {
-                const int pos = e / cpg;
-                const float d = base[pos * zs + (e - pos * cpg)] - mean;
-                q += d * d;
+                const int pos = fdiv(e, A.dcpg[l]);
+                const int off = pos * zs + (e - pos * cpg);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sm[u] += base[u][off];
             }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
-            if (lane == 0) {
-                gstat[pi * 2] = mean;
-                gstat[pi * 2 + 1] = rstd;
-                if (Ly.gst) {
-                    Ly.gst[((row0 + lr) * G + g) * 2] = mean;
-                    Ly.gst[((row0 + lr) * G + g) * 2 + 1] = rstd;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mean[u] = wave_sum(sm[u]) / (float)cnt;
+            for (int e = lane; e < cnt; e += 64) {
+                const int pos = fdiv(e, A.dcpg[l]);
+                const int off = pos * zs + (e - pos * cpg);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = base[u][off] - mean[u];
+                    q[u] += d * d;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float rstd = 1.0f / sqrtf(wave_sum(q[u]) / (float)cnt + 1e-5f);
+                const int pi = pi0 + u;
+                if (lane == 0 && pi < npairs) {
+                    gstat[pi * 2] = mean[u];
+                    gstat[pi * 2 + 1] = rstd;
+                    if (Ly.gst) {
+                        Ly.gst[(row0 * G + pi) * 2] = mean[u];
+                        Ly.gst[(row0 * G + pi) * 2 + 1] = rstd;
+                    }
                 }
             }
         }
+        MARL_TS();
         __syncthreads();
+        MARL_TS();
         if (l + 1 < A.L) {
-            // ---- normalise + SiLU while gathering the next layer's im2col tile (3x3, stride 2,
-            // pad 1; k = tap * cin + ci, float4 along ci)
-            const CnnFwdLayer& Nx = A.layer[l + 1];
-            const int s1 = A.s[l + 1], c4 = s1 >> 2, P1 = Nx.P, hin = Ly.hout, hout = Nx.hout;
-            const int M1 = nrow * P1;
-            const int tot = (((M1 + 15) & ~15) + 1) * c4;
-            for (int idx = tid; idx < tot; idx += nthreads) {
-                const int mo = idx / c4, k = (idx - mo * c4) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mo < M1 && k < Nx.K) {
-                    const int lr = mo / P1, opos = mo - lr * P1;
-                    const int tap = k / cout, ci = k - tap * cout;
-                    const int kh = tap / 3, kw = tap - 3 * kh;
-                    const int oy = opos / hout, ox = opos - oy * hout;
-                    const int iy = 2 * oy - 1 + kh, ix = 2 * ox - 1 + kw;
-                    if (iy >= 0 && iy < hin && ix >= 0 && ix < hin) {
-                        const float4 z = *reinterpret_cast<const float4*>(Zb + (lr * P + iy * hin + ix) * zs + ci);
-                        const int g = ci / cpg;
-                        const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
-                        const float4 gm = *reinterpret_cast<const float4*>(Ly.gamma + ci);
-                        const float4 bt = *reinterpret_cast<const float4*>(Ly.beta + ci);
-                        v.x = cnn_silu((z.x - mean) * rstd * gm.x + bt.x);
-                        v.y = cnn_silu((z.y - mean) * rstd * gm.y + bt.y);
-                        v.z = cnn_silu((z.z - mean) * rstd * gm.z + bt.z);
-                        v.w = cnn_silu((z.w - mean) * rstd * gm.w + bt.w);
-                    }
-                }
-                *reinterpret_cast<float4*>(T + mo * s1 + k) = v;
+            // ---- normalise + SiLU in place: the next layer's NHWC input
+            const int c4 = cout >> 2;
+            for (int idx = tid; idx < M * c4; idx += nthreads) {
+                const int m = fdiv(idx, A.dc4o[l]), c = (idx - m * c4) * 4;
+                const int lr = fdiv(m, A.dP[l]);
+                const int g = fdiv(c, A.dcpg[l]);
+                const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+                float4* zp = reinterpret_cast<float4*>(Zb + m * zs + c);
+                const float4 z = *zp;
+                const float4 gm = *reinterpret_cast<const float4*>(Ly.gamma + c);
+                const float4 bt = *reinterpret_cast<const float4*>(Ly.beta + c);
+                float4 v;
+                v.x = cnn_silu((z.x - mean) * rstd * gm.x + bt.x);
+                v.y = cnn_silu((z.y - mean) * rstd * gm.y + bt.y);
+                v.z = cnn_silu((z.z - mean) * rstd * gm.z + bt.z);
+                v.w = cnn_silu((z.w - mean) * rstd * gm.w + bt.w);
+                *zp = v;
             }
         } else {
             // ---- last layer: features in the reference's (C, H, W) flatten order -> U
             const int E = P * cout;
             for (int idx = tid; idx < nrow * E; idx += nthreads) {
-                const int lr = idx / E, e = idx - lr * E;
-                const int c = e / P, pos = e - c * P;
-                const int g = c / cpg;
+                const int lr = fdiv(idx, A.dE), e = idx - lr * E;
+                const int c = fdiv(e, A.dP[l]), pos = e - c * P;
+                const int g = fdiv(c, A.dcpg[l]);
                 const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
                 const float zv = Zb[(lr * P + pos) * zs + c];
                 A.u[(row0 + lr) * (int64_t)A.ldu + e] = cnn_silu((zv - mean) * rstd * Ly.gamma[c] + Ly.beta[c]);
             }
         }
+        MARL_TS();
         __syncthreads();
+        MARL_TS();
     }
 }
 
-static int cnn_lds_stride(int ldk) { return (ldk & 7) == 4 ? ldk : ldk + 4; }
-
-// LDS floats for rb patches per workgroup; fills a.s / a.off_*
+// LDS floats for rb patches per workgroup; fills the launcher-owned fields of `a`
 static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
-    size_t tile = 0, zb = 0, st = 0;
+    size_t b0 = 0, b1 = 0, st = 0;
     for (int l = 0; l < a.L; ++l) {
         const CnnFwdLayer& L = a.layer[l];
-        a.s[l] = cnn_lds_stride(L.ldk);
-        const size_t rows16 = (((size_t)rb * L.P + 15) & ~(size_t)15) + 1;
-        // + 16 floats: the last k-step of the last row may read past the row stride
-        const size_t t = rows16 * a.s[l] + 16;
-        tile = t > tile ? t : tile;
+        a.dP[l] = make_fdiv(L.P);
+        a.dhout[l] = make_fdiv(L.hout);
+        a.dcin[l] = make_fdiv(L.cin);
+        a.dcpg[l] = make_fdiv(L.cout / L.G);
+        a.dG[l] = make_fdiv(L.G);
+        a.dNT[l] = make_fdiv((L.cout + 15) / 16);
+        a.dc4o[l] = make_fdiv(L.cout / 4);
         const size_t z = (size_t)rb * L.P * (L.cout + 4);
-        zb = z > zb ? z : zb;
+        if (l & 1)
+            b1 = z > b1 ? z : b1;
+        else
+            b0 = z > b0 ? z : b0;
         const size_t g = (size_t)rb * L.G * 2;
         st = g > st ? g : st;
     }
-    tile = (tile + 3) & ~(size_t)3;
-    zb = (zb + 3) & ~(size_t)3;
+    const int ff = a.f * a.f;
+    size_t patch = (size_t)rb * a.layer[0].cin * ff;
+    patch = (patch + 3) & ~(size_t)3;
     a.rb = rb;
-    a.off_z = (int)tile;
-    a.off_stat = (int)(tile + zb);
-    return tile + zb + st;
+    a.dpe = make_fdiv(a.layer[0].cin * ff);
+    a.dff = make_fdiv(ff);
+    a.df = make_fdiv(a.f);
+    a.dE = make_fdiv(a.layer[a.L - 1].P * a.layer[a.L - 1].cout);
+    a.off_b0 = (int)patch;
+    a.off_b1 = (int)(patch + b0);
+    a.off_stat = (int)(patch + b0 + b1);
+    return patch + b0 + b1 + st;
 }
 
 int cnn_fwd_supported(const CnnFwdArgs& a0) {
@@ -328,10 +412,18 @@ int cnn_fwd_supported(const CnnFwdArgs& a0) {
 
 int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
     if (a.rows <= 0) return MARL_OK;
-    // as many patches per workgroup as fit two workgroups per CU (the conv weights are re-read
-    // from L2 by every workgroup), but keep >= 256 workgroups
-    int rb = 8;
-    while (rb > 1 && (cnn_fwd_plan(a, rb) * sizeof(float) > 72 * 1024 || cdiv(a.rows, rb) < 256)) --rb;
+    // as many patches per workgroup as fit three workgroups per CU (the conv weights are
+    // re-read from L2 by every workgroup), but keep >= 256 workgroups
+    static int rb_max = 0, lds_cap = 0;
+    if (!rb_max) {
+        const char* e = getenv("MARL_CNN_RB");
+        rb_max = e ? atoi(e) : 8;
+        if (rb_max < 1 || rb_max > 16) rb_max = 8;  // <= 16: per-patch LDS tables
+        const char* c = getenv("MARL_CNN_LDS_KB");
+        lds_cap = c ? atoi(c) : 52;
+    }
+    int rb = rb_max;
+    while (rb > 1 && (cnn_fwd_plan(a, rb) * sizeof(float) > (size_t)lds_cap * 1024 || cdiv(a.rows, rb) < 256)) --rb;
     const size_t lds = cnn_fwd_plan(a, rb) * sizeof(float);
     if (lds > 144 * 1024) {
         set_error("fused CNN forward: window %d outside its range", a.f);
@@ -343,8 +435,17 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         raised = true;
     }
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts = nullptr;
+    static int calls = 0;
+    const int rec = ts_begin(&d_ts, calls++);
+    a.ts = rec ? d_ts : nullptr;
+#endif
     hipLaunchKernelGGL(cnn_fwd_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
     MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec) ts_report("cnn_fwd", d_ts, 8);
+#endif
     return MARL_OK;
 }
 

@@ -291,6 +291,29 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
 // ---------------------------------------------------------------------------
 // Fused per-step CNN forward (cnn.hip): gather + [im2col -> conv -> GroupNorm -> SiLU] x L
 // ---------------------------------------------------------------------------
+// In-kernel phase timestamps (make EXTRA=-DMARL_KERNEL_TS): lane 0 of every wave of one
+// workgroup records wall_clock64() (100 MHz) at each MARL_TS() in kernel order.
+#ifdef MARL_KERNEL_TS
+#define MARL_TS_DECL(ptr) long long* ts_ = (ptr); int tsi_ = 0
+#define MARL_TS()                                                                         \
+    if (ts_ && (threadIdx.x & 63) == 0 && blockIdx.x == 37 && blockIdx.y == 0 && tsi_ < 48) \
+    ts_[(threadIdx.x >> 6) * 48 + tsi_++] = wall_clock64()
+int ts_begin(long long** dev, int call);                 // returns 1 when this call records
+void ts_report(const char* tag, long long* dev, int waves);
+#else
+#define MARL_TS_DECL(ptr)
+#define MARL_TS()
+#endif
+
+// division by a launch-invariant divisor: q = umulhi(n, m), exact for n, d < 65536
+struct FDiv {
+    uint32_t d, m;
+};
+inline FDiv make_fdiv(int d) { return FDiv{(uint32_t)d, (uint32_t)(((1ull << 32) / (uint64_t)d) + 1)}; }
+__device__ __forceinline__ int fdiv(int n, FDiv f) {
+    return f.d == 1 ? n : (int)__umulhi((uint32_t)n, f.m);
+}
+
 struct CnnFwdLayer {
     const float *w, *bias, *gamma, *beta;  // packed conv weight [cout][ldk] (k = tap * cin + ci)
     float* cols;                           // [R * P][ldk] im2col rows kept for backward (or null)
@@ -309,9 +332,15 @@ struct CnnFwdArgs {
     float* u;  // [R][ldu], feature index c * P_last + pos (the reference's NCHW flatten)
     int ldu;
     // filled by the launcher
-    int rb;                         // patches per workgroup
-    int s[MARL_MAX_CNN_LAYERS];     // LDS row stride of layer l's im2col tile
-    int off_z, off_stat;            // LDS float offsets
+    int rb;                       // patches per workgroup
+    int off_b0, off_b1, off_stat; // LDS float offsets: even / odd layers' output, statistics
+    FDiv dP[MARL_MAX_CNN_LAYERS], dhout[MARL_MAX_CNN_LAYERS], dcin[MARL_MAX_CNN_LAYERS],
+        dcpg[MARL_MAX_CNN_LAYERS], dG[MARL_MAX_CNN_LAYERS], dNT[MARL_MAX_CNN_LAYERS],
+        dc4o[MARL_MAX_CNN_LAYERS];
+    FDiv dpe, dff, df, dE;
+#ifdef MARL_KERNEL_TS
+    long long* ts;  // phase timestamps of one workgroup (debug builds only)
+#endif
 };
 int cnn_fwd_supported(const CnnFwdArgs& a);
 int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st);
