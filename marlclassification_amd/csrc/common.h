@@ -84,7 +84,26 @@ constexpr int kMaxGemmBatch = 4;
 struct GemmBatch {
     GemmProb p[kMaxGemmBatch];
     int count;
+    int gx, gy;   // logical tile grid (row blocks, column blocks); filled by the launcher
+    int xcd_map;  // 1: 1-D launch with the XCD-aware tile order below
 };
+
+// Tile order for tiled kernels whose neighbouring tiles share operand panels.  Workgroup b of
+// a 1-D launch lands on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch) and every XCD
+// has a private L2, so XCD x gets a CONTIGUOUS chunk of the tile sequence (bijective for any
+// tile count), ordered column block fastest: the tiles that run together on one XCD read the
+// same A row panel (and the small B) from its L2 instead of HBM.
+__device__ __forceinline__ void xcd_tile(unsigned gx, unsigned gy, unsigned gz, unsigned& bx,
+                                         unsigned& by, unsigned& bz) {
+    const unsigned T = gx * gy * gz, L = blockIdx.x;
+    const unsigned per = T >> 3, rem = T & 7, xcd = L & 7, slot = L >> 3;
+    const unsigned q = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    bz = q / (gx * gy);
+    const unsigned r = q - bz * gx * gy;
+    bx = r / gy;
+    by = r - bx * gy;
+}
+int xcd_map_enabled();
 
 GemmProb gemm_prob(const float* a, int lda, const float* b, int ldb, int k, float* c, int ldc,
                    int m, int n, const float* bias = nullptr, int accumulate = 0);

@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;          // row depth of one staged tile of the TN kernel
 
+
 // Gate non-linearities of the fused LSTM epilogue: v_exp_f32 / v_rcp_f32 based (~1e-7
 // absolute error, well inside the 1e-5 parity budget; checked by the golden-vector tests).
 // The accurate libm forms cost ~10 us per launch in the epilogue of a 120 us kernel.
@@ -30,32 +31,50 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
 }
 
-template <int BM, int BN, int WM, int WN, bool LSTM, int BK = 16>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
+// LDS-only workgroup barrier: the prefetch loads of the next K tile stay in flight across it
+// (a plain __syncthreads() also drains vmcnt).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// GROUPS = 2 ("ping-pong"): 8 waves, two per SIMD.  Group g owns rows [g * BM, (g + 1) * BM) of
+// a (2 * BM) x BN tile and half of the B rows of every K tile.  The groups run the same loop
+// half a step apart - while one is in its matrix phase (64 back-to-back MFMAs per wave) the
+// other waits for its prefetch, writes the next tile to LDS and issues the following loads -
+// so the matrix pipe of every SIMD always has exactly one wave feeding it.  Two co-resident
+// 4-wave workgroups running the plain loop (GROUPS = 1) start together and tend to stay in
+// lockstep, staging at the same time with the pipe idle.
+template <int BM, int BN, int WM, int WN, bool LSTM, int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch batch) {
+    constexpr int BK = 32;
     constexpr int LDS_K = BK + 4;  // padded LDS row stride (floats): conflict-free b128 reads
     constexpr int KC = BK / 4;     // float4 chunks per tile row
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int A_CH = BM * (BK / 4) / 256;
-    constexpr int B_CH = BN * (BK / 4) / 256;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+    constexpr int A_CH = BM * KC / 256;            // A chunks per thread (own row half)
+    constexpr int B_CH = BN * KC / 256 / GROUPS;   // B chunks per thread (own share of the rows)
+    constexpr int BUF = (GROUPS * BM + BN) * LDS_K;
+    static_assert(WM * WN == 4, "4 waves per group");
+    static_assert(A_CH >= 1 && A_CH <= 4 && B_CH >= 1 && B_CH <= 4, "1..4 chunks per thread");
     static_assert(!LSTM || (WN == 1 && BN == 128), "LSTM tile = 4 gates x 32 units");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][(BM + BN) * LDS_K]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF]
 
-    const GemmProb& P = batch.p[blockIdx.z];
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (batch.xcd_map) xcd_tile(batch.gx, batch.gy, batch.count, bx, by, bz);
+    const GemmProb& P = batch.p[bz];
     const int M = P.m;
     const int N = P.n;  // LSTM: number of hidden units (B has 4*N rows)
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * (LSTM ? 32 : BN);
-    if (m0 >= M || n0 >= N) return;
+    const int n0 = by * (LSTM ? 32 : BN);
+    if ((int)(bx * (BM * GROUPS)) >= M || n0 >= N) return;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;  // thread index inside its group
+    const int grp = GROUPS == 2 ? (int)(threadIdx.x >> 8) : 0;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN;
     const int wn = wave % WN;
+    const int m0 = bx * (BM * GROUPS) + grp * BM;  // first row of this group
 
     const int t0 = (P.seg[0].k + BK - 1) / BK;
     const int t1 = P.nseg > 1 ? (P.seg[1].k + BK - 1) / BK : 0;
@@ -69,95 +88,108 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Per-thread staging coordinates (fixed for the whole K loop): chunk c covers tile row
-    // c / KC, floats [(c % KC) * 4, +4).  Rows beyond M / N are clamped to the last valid row
+    // Staging: thread t of a group moves A chunks c = t + 256 * i (tile row c / KC of the group's
+    // rows) and B chunks of the group's share of the B rows, floats [(t % KC) * 4, +4) of the K
+    // tile.  Addresses are a UNIFORM base (segment pointer + k0, advanced on the scalar unit)
+    // plus a fixed per-thread 32-bit byte offset, so the steady state issues no vector integer
+    // work beside the matrix instructions.  Rows beyond M / N are clamped to the last valid row
     // (their results are never stored).
-    const float* arow0[A_CH];
-    const float* arow1[A_CH];
-    const float* brow0[B_CH];
-    const float* brow1[B_CH];
-    int koff[A_CH > B_CH ? A_CH : B_CH];
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        const int c = tid + 256 * i;
-        int gm = m0 + c / KC;
-        gm = gm < M ? gm : M - 1;
-        arow0[i] = P.seg[0].a + (size_t)gm * P.seg[0].lda;
-        arow1[i] = P.nseg > 1 ? P.seg[1].a + (size_t)gm * P.seg[1].lda : arow0[i];
-        koff[i] = (c % KC) * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c / KC;
-        int gn;
-        if (LSTM) {
-            int unit = n0 + (row & 31);
-            unit = unit < N ? unit : N - 1;
-            gn = (row >> 5) * N + unit;
-        } else {
-            gn = n0 + row;
-            gn = gn < N ? gn : N - 1;
-        }
-        brow0[i] = P.seg[0].b + (size_t)gn * P.seg[0].ldb;
-        brow1[i] = P.nseg > 1 ? P.seg[1].b + (size_t)gn * P.seg[1].ldb : brow0[i];
-        koff[i] = (c % KC) * 4;  // same for A and B chunks (A_CH == B_CH or KC-periodic)
-    }
-    const int K4_0 = (P.seg[0].k + 3) & ~3;
-    const int K4_1 = P.nseg > 1 ? (P.seg[1].k + 3) & ~3 : 4;
-
-    // Loads are UNCONDITIONAL from clamped, always-valid addresses: a predicated load makes
-    // hipcc branch around it and drain vmcnt per load (one L2 round trip each).  K columns
-    // past the end are zeroed on the B side when the tile goes to LDS (weights are finite, so
-    // finite-garbage * 0 is exact).
-    // One register set: tile t+1 is requested right after the barrier of tile t and lands
-    // while tile t is computed.  (A second set / prefetch distance 2 was measured: no gain,
-    // the fp32 MFMA phase of ~3.5 us already covers the L2 latency.)
-    float4 raX0, raX1, raX2, raX3, rbX0, rbX1, rbX2, rbX3;
-    float mkX0 = 1.f, mkX1 = 1.f, mkX2 = 1.f, mkX3 = 1.f;
-#define MARL_LOAD_ONE(S, idx_, ia_, ib_)                                                   \
-    {                                                                                      \
-        const int k_ = k0_ + koff[ia_];                                                    \
-        const int kc_ = k_ < K4_ ? k_ : K4_ - 4;                                           \
-        ra##S##idx_ = *reinterpret_cast<const float4*>((s1_ ? arow1[ia_] : arow0[ia_]) + kc_); \
-        rb##S##idx_ = *reinterpret_cast<const float4*>((s1_ ? brow1[ib_] : brow0[ib_]) + kc_); \
-        mk##S##idx_ = k_ < K4_ ? 1.f : 0.f;                                                \
-    }
-#define MARL_LOAD_TILE(S, tile_)                                                           \
-    {                                                                                      \
-        const int s1_ = (tile_) >= t0 ? 1 : 0;                                             \
-        const int k0_ = (s1_ ? (tile_) - t0 : (tile_)) * BK;                               \
-        const int K4_ = s1_ ? K4_1 : K4_0;                                                 \
-        MARL_LOAD_ONE(S, 0, 0, 0)                                                          \
-        if (A_CH > 1) MARL_LOAD_ONE(S, 1, 1 % A_CH, 1 % B_CH)                              \
-        if (A_CH > 2) MARL_LOAD_ONE(S, 2, 2 % A_CH, 2 % B_CH)                              \
-        if (A_CH > 3) MARL_LOAD_ONE(S, 3, 3 % A_CH, 3 % B_CH)                              \
-    }
-#define MARL_STORE_ONE(S, idx_)                                                            \
+    const int koff = (tid % KC) * 4;
+    uint32_t aofX0 = 0, aofX1 = 0, aofX2 = 0, aofX3 = 0, bofX0 = 0, bofX1 = 0, bofX2 = 0, bofX3 = 0;
+    const char* abase = nullptr;
+    const char* bbase = nullptr;
+    int K4cur = 0;
+#define MARL_SETA(idx_, sg_)                                                               \
     if (A_CH > (idx_)) {                                                                   \
-        const int c_ = tid + 256 * (idx_);                                                 \
-        *reinterpret_cast<float4*>(As_ + (c_ / KC) * LDS_K + (c_ % KC) * 4) = ra##S##idx_; \
-        float4 v_ = rb##S##idx_;                                                           \
-        v_.x *= mk##S##idx_;                                                               \
-        v_.y *= mk##S##idx_;                                                               \
-        v_.z *= mk##S##idx_;                                                               \
-        v_.w *= mk##S##idx_;                                                               \
-        *reinterpret_cast<float4*>(Bs_ + (c_ / KC) * LDS_K + (c_ % KC) * 4) = v_;          \
+        int gm_ = m0 + (tid + 256 * (idx_)) / KC;                                          \
+        gm_ = gm_ < M ? gm_ : M - 1;                                                       \
+        aofX##idx_ = ((uint32_t)gm_ * (uint32_t)P.seg[sg_].lda + (uint32_t)koff) * 4u;     \
     }
-#define MARL_STORE_TILE(S, buf_)                                                           \
+#define MARL_SETB(idx_, sg_)                                                               \
+    if (B_CH > (idx_)) {                                                                   \
+        const int row_ = (tid + 256 * (idx_)) / KC + grp * (BN / GROUPS);                  \
+        int gn_;                                                                           \
+        if (LSTM) {                                                                        \
+            int unit_ = n0 + (row_ & 31);                                                  \
+            unit_ = unit_ < N ? unit_ : N - 1;                                             \
+            gn_ = (row_ >> 5) * N + unit_;                                                 \
+        } else {                                                                           \
+            gn_ = n0 + row_;                                                               \
+            gn_ = gn_ < N ? gn_ : N - 1;                                                   \
+        }                                                                                  \
+        bofX##idx_ = ((uint32_t)gn_ * (uint32_t)P.seg[sg_].ldb + (uint32_t)koff) * 4u;     \
+    }
+#define MARL_SET_SEG(sg_)                                                                  \
     {                                                                                      \
-        float* As_ = smem + (buf_) * (BM + BN) * LDS_K;                                    \
-        float* Bs_ = As_ + BM * LDS_K;                                                     \
-        MARL_STORE_ONE(S, 0)                                                               \
-        MARL_STORE_ONE(S, 1)                                                               \
-        MARL_STORE_ONE(S, 2)                                                               \
-        MARL_STORE_ONE(S, 3)                                                               \
+        MARL_SETA(0, sg_) MARL_SETA(1, sg_) MARL_SETA(2, sg_) MARL_SETA(3, sg_)            \
+        MARL_SETB(0, sg_) MARL_SETB(1, sg_) MARL_SETB(2, sg_) MARL_SETB(3, sg_)            \
+        abase = reinterpret_cast<const char*>(P.seg[sg_].a);                               \
+        bbase = reinterpret_cast<const char*>(P.seg[sg_].b);                               \
+        K4cur = (P.seg[sg_].k + 3) & ~3;                                                   \
     }
+
+    // Loads are UNCONDITIONAL (a predicated load makes hipcc branch around it and drain vmcnt
+    // per load).  Only the LAST K tile of a segment can reach past round4(K): there the chunk
+    // address is clamped and the B side is zeroed when the tile goes to LDS (weights are
+    // finite, so finite-garbage * 0 is exact); all other tiles take the mask-free path.
+    float4 raX0, raX1, raX2, raX3, rbX0, rbX1, rbX2, rbX3;
+    float mkX = 1.f;
+    bool masked = false;  // uniform: the tile held in the staging registers is a tail tile
+#define MARL_LOADA(idx_, d_) \
+    if (A_CH > (idx_)) raX##idx_ = *reinterpret_cast<const float4*>(abase + (aofX##idx_ + (d_)));
+#define MARL_LOADB(idx_, d_) \
+    if (B_CH > (idx_)) rbX##idx_ = *reinterpret_cast<const float4*>(bbase + (bofX##idx_ + (d_)));
+#define MARL_LOAD_ALL(d_)                                                                  \
+    MARL_LOADA(0, d_) MARL_LOADA(1, d_) MARL_LOADA(2, d_) MARL_LOADA(3, d_)                \
+    MARL_LOADB(0, d_) MARL_LOADB(1, d_) MARL_LOADB(2, d_) MARL_LOADB(3, d_)
+#define MARL_LOAD_TILE(tile_)                                                              \
+    {                                                                                      \
+        if ((tile_) == t0) MARL_SET_SEG(1)                                                 \
+        const int k0_ = ((tile_) >= t0 ? (tile_) - t0 : (tile_)) * BK;                     \
+        masked = k0_ + BK > K4cur;                                                         \
+        if (!masked) {                                                                     \
+            MARL_LOAD_ALL(0u)                                                              \
+        } else {                                                                           \
+            const int k_ = k0_ + koff;                                                     \
+            const uint32_t d_ = k_ < K4cur ? 0u : (uint32_t)((K4cur - 4 - k_) * 4);        \
+            mkX = k_ < K4cur ? 1.f : 0.f;                                                  \
+            MARL_LOAD_ALL(d_)                                                              \
+        }                                                                                  \
+        abase += BK * 4;                                                                   \
+        bbase += BK * 4;                                                                   \
+    }
+#define MARL_STOREA(idx_)                                                                  \
+    if (A_CH > (idx_))                                                                     \
+        *reinterpret_cast<float4*>(As_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = raX##idx_;
+#define MARL_STOREB(idx_)                                                                  \
+    if (B_CH > (idx_)) {                                                                   \
+        if (masked) {                                                                      \
+            rbX##idx_.x *= mkX;                                                            \
+            rbX##idx_.y *= mkX;                                                            \
+            rbX##idx_.z *= mkX;                                                            \
+            rbX##idx_.w *= mkX;                                                            \
+        }                                                                                  \
+        *reinterpret_cast<float4*>(Bs_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = rbX##idx_; \
+    }
+#define MARL_STORE_TILE(buf_)                                                              \
+    {                                                                                      \
+        float* As_ = smem + (buf_) * BUF + grp * BM * LDS_K;                               \
+        float* Bs_ = smem + (buf_) * BUF + (GROUPS * BM + grp * (BN / GROUPS)) * LDS_K;    \
+        MARL_STOREA(0) MARL_STOREA(1) MARL_STOREA(2) MARL_STOREA(3)                        \
+        MARL_STOREB(0) MARL_STOREB(1) MARL_STOREB(2) MARL_STOREB(3)                        \
+    }
+    // Matrix phase: all fragments of an 8-deep K group are read first, then the MFMAs walk the
+    // accumulators round-robin (k-major), so that consecutive matrix instructions never hit
+    // the same accumulator and nothing else is issued between them.
+#define MARL_MFMA_Q(q_)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].q_, b4[j].q_, acc[i][j], 0, 0, 0);
 #define MARL_COMPUTE_TILE(buf_)                                                            \
     {                                                                                      \
-        const float* As = smem + (buf_) * (BM + BN) * LDS_K +                              \
-                          (wm * (BM / WM) + frag_row) * LDS_K + frag_k;                    \
-        const float* Bs = smem + (buf_) * (BM + BN) * LDS_K + BM * LDS_K +                 \
+        const float* As = smem + (buf_) * BUF +                                            \
+                          (grp * BM + wm * (BM / WM) + frag_row) * LDS_K + frag_k;         \
+        const float* Bs = smem + (buf_) * BUF + GROUPS * BM * LDS_K +                      \
                           (wn * (BN / WN) + frag_row) * LDS_K + frag_k;                    \
         _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                            \
             float4 a4[TM], b4[TN];                                                         \
@@ -165,35 +197,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmBatch batch) {
                 a4[i] = *reinterpret_cast<const float4*>(As + i * 32 * LDS_K + kk * 8);    \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                 \
                 b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);    \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                           \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0); \
-                }                                                                          \
+            MARL_MFMA_Q(x) MARL_MFMA_Q(y) MARL_MFMA_Q(z) MARL_MFMA_Q(w)                    \
         }                                                                                  \
     }
-    static_assert(A_CH == B_CH && A_CH <= 4, "square tiles, at most 4 chunks per thread");
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
-    MARL_LOAD_TILE(X, 0)
-    for (int tile = 0; tile < T; ++tile) {
+    MARL_SET_SEG(0)
+    MARL_LOAD_TILE(0)
+    if (GROUPS == 1) {
         // One barrier per tile: LDS buffer b was last read two tiles ago and every wave has
         // passed the previous tile's barrier only after finishing those reads.
-        const int buf = tile & 1;
-        MARL_STORE_TILE(X, buf)
-        __syncthreads();
-        if (tile + 1 < T) MARL_LOAD_TILE(X, tile + 1)
-        MARL_COMPUTE_TILE(buf)
+        for (int tile = 0; tile < T; ++tile) {
+            const int buf = tile & 1;
+            MARL_STORE_TILE(buf)
+            lds_barrier();
+            if (tile + 1 < T) MARL_LOAD_TILE(tile + 1)
+            MARL_COMPUTE_TILE(buf)
+        }
+    } else {
+        // Half-steps h = 0, 1, 2, ...: group 0 computes tile t at h = 2t and stages tile t + 1
+        // at h = 2t + 1; group 1 stages tile t + 1 at h = 2t (one step ahead, so that its half
+        // of the B rows is in LDS before group 0 needs it) and computes tile t at h = 2t + 1.
+        // A barrier closes every half-step; both groups execute the same number of them.
+        MARL_STORE_TILE(0)
+        if (grp == 1 && T > 1) MARL_LOAD_TILE(1)
+        lds_barrier();
+        if (grp == 0) {
+            for (int tile = 0; tile < T; ++tile) {
+                if (tile + 1 < T) MARL_LOAD_TILE(tile + 1)
+                MARL_COMPUTE_TILE(tile & 1)
+                lds_barrier();
+                if (tile + 1 < T) MARL_STORE_TILE((tile + 1) & 1)
+                lds_barrier();
+            }
+        } else {
+            for (int tile = 0; tile < T; ++tile) {
+                if (tile + 1 < T) MARL_STORE_TILE((tile + 1) & 1)
+                if (tile + 2 < T) MARL_LOAD_TILE(tile + 2)
+                lds_barrier();
+                MARL_COMPUTE_TILE(tile & 1)
+                lds_barrier();
+            }
+        }
     }
-#undef MARL_LOAD_ONE
+#undef MARL_SETA
+#undef MARL_SETB
+#undef MARL_SET_SEG
+#undef MARL_LOADA
+#undef MARL_LOADB
+#undef MARL_LOAD_ALL
+#undef MARL_LOAD_TILE
+#undef MARL_STOREA
+#undef MARL_STOREB
 #undef MARL_STORE_TILE
 #undef MARL_COMPUTE_TILE
-#undef MARL_LOAD_TILE
-#undef MARL_STORE_ONE
+#undef MARL_MFMA_Q
 
     // ---- epilogue: acc[i][j][r] is C[row(r), col], col = lane & 31,
     //      row(r) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -258,7 +318,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       float* __restrict__ out, int ldo,
                                                       int64_t out_split_stride, int NI, int NJ,
                                                       int64_t rows, int64_t rows_per_split,
-                                                      float* __restrict__ csum) {
+                                                      float* __restrict__ csum, int gx, int gy,
+                                                      int gz) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_CH = BK * (BM / 4) / 256;
@@ -266,9 +327,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
 
-    const int i0 = blockIdx.x * BM;
-    const int j0 = blockIdx.y * BN;
-    const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+    // gx > 0: 1-D launch, XCD-aware order (the tiles of one row slab run on one XCD, so its A
+    // and B row panels come from that XCD's L2 for all but the first tile)
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (gx > 0) xcd_tile(gx, gy, gz, bx, by, bz);
+    const int i0 = bx * BM;
+    const int j0 = by * BN;
+    const int64_t r_begin = (int64_t)bz * rows_per_split;
     int64_t r_end = r_begin + rows_per_split;
     if (r_end > rows) r_end = rows;
     const int NI4 = (NI + 3) & ~3, NJ4 = (NJ + 3) & ~3;
@@ -307,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     float mk0 = 1.f, mk1 = 1.f;
     // column sums of A (the bias gradient that goes with this weight gradient): taken for
     // free from the staged A tiles by the workgroups of the first column-tile
-    const bool do_csum = csum != nullptr && blockIdx.y == 0;
+    const bool do_csum = csum != nullptr && by == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define MARL_TN_LOAD(tile_)                                                            \
     {                                                                                  \
@@ -394,7 +459,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 t.z += u.z;
                 t.w += u.w;
             }
-            float* co = csum + (size_t)blockIdx.z * NI;
+            float* co = csum + (size_t)bz * NI;
             const int ic = i0 + tid * 4;
             if (ic < NI) co[ic] = t.x;
             if (ic + 1 < NI) co[ic + 1] = t.y;
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
     }
 
-    float* o = out + (size_t)blockIdx.z * out_split_stride;
+    float* o = out + (size_t)bz * out_split_stride;
     const int row_h = 4 * (lane >> 5);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -476,10 +541,15 @@ void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb,
 static void prof_before(int cls, hipStream_t st);
 static void prof_after(int cls, hipStream_t st);
 
-template <int BM, int BN, int WM, int WN, bool LSTM, int BKT>
-static int launch_nt_variant(dim3 grid, const GemmBatch& batch, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, BKT>;
+template <int BM, int BN, int WM, int WN, bool LSTM, int GROUPS>
+static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t st) {
+    GemmBatch batch = batch_in;
+    batch.gx = (int)grid.x;
+    batch.gy = (int)grid.y;
+    batch.xcd_map = xcd_map_enabled();
+    if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
+    constexpr size_t lds = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
+    auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, GROUPS>;
     if (lds > 64 * 1024) {
         static bool raised = false;  // opt in to > 64 KiB of dynamic LDS once per kernel
         if (!raised) {
@@ -488,17 +558,29 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch, hipStream_t st) 
             raised = true;
         }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * GROUPS), lds, st, batch);
     return MARL_OK;
 }
 
-static int gemm_bk() {
-    static int bk = 0;
-    if (!bk) {
-        const char* e = getenv("MARL_GEMM_BK");
-        bk = (e && atoi(e) == 16) ? 16 : 32;
+int xcd_map_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MARL_XCD_MAP");
+        on = (e && e[0] == '1') ? 1 : 0;  // opt-in: measured neutral-to-negative on this workload
     }
-    return bk;
+    return on;
+}
+
+// 1 = plain 4-wave loop (default), 2 = ping-pong wave groups (MARL_GEMM_GROUPS=2).  Measured on
+// MI355X: the two-group schedule gains 2-7 % on single large products (M = 65536) but loses
+// on this workload's small / batched products (bigger tiles -> worse tail), so it is opt-in.
+static int gemm_groups() {
+    static int g = 0;
+    if (!g) {
+        const char* e = getenv("MARL_GEMM_GROUPS");
+        g = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    return g;
 }
 
 static int check_prob(const GemmProb& p) {
@@ -510,6 +592,12 @@ static int check_prob(const GemmProb& p) {
             set_error("gemm: bad operand (seg %d: a=%p lda=%d b=%p ldb=%d k=%d)", s, (const void*)g.a,
                       g.lda, (const void*)g.b, g.ldb, g.k);
             return MARL_EINVAL;
+        }
+        // the staging offsets are 32-bit byte offsets from the segment base
+        const int64_t brows = p.h_next ? 4 * (int64_t)p.n : (int64_t)p.n;
+        if ((int64_t)p.m * g.lda >= (1ll << 30) || brows * g.ldb >= (1ll << 30)) {
+            set_error("gemm: operand of seg %d spans more than 4 GiB", s);
+            return MARL_ELIMIT;
         }
     }
     if (p.m <= 0 || p.n <= 0) {
@@ -532,17 +620,19 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
     }
     prof_before(1, st);
     if (blocks128 >= 256 && max_n >= 96) {
-        dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
-        if (gemm_bk() == 32)
-            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 32>(grid, batch, st)));
+        const int g = gemm_groups();
+        dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
+        if (g == 2)
+            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 2>(grid, batch, st)));
         else
-            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 16>(grid, batch, st)));
+            MARL_TRY((launch_nt_variant<128, 128, 2, 2, false, 1>(grid, batch, st)));
     } else {
-        dim3 grid((unsigned)cdiv(max_m, 64), (unsigned)cdiv(max_n, 64), (unsigned)batch.count);
-        if (gemm_bk() == 32)
-            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 32>(grid, batch, st)));
+        const int g = gemm_groups();
+        dim3 grid((unsigned)cdiv(max_m, 64 * g), (unsigned)cdiv(max_n, 64), (unsigned)batch.count);
+        if (g == 2)
+            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 2>(grid, batch, st)));
         else
-            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 16>(grid, batch, st)));
+            MARL_TRY((launch_nt_variant<64, 64, 2, 2, false, 1>(grid, batch, st)));
     }
     prof_after(1, st);
     MARL_LAUNCH_CHECK();
@@ -607,12 +697,13 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
         max_m = p.m > max_m ? p.m : max_m;
         max_n = p.n > max_n ? p.n : max_n;
     }
-    dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
+    const int g = gemm_groups();
+    dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
     prof_before(0, st);
-    if (gemm_bk() == 32)
-        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 32>(grid, batch, st)));
+    if (g == 2)
+        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 2>(grid, batch, st)));
     else
-        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 16>(grid, batch, st)));
+        MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 1>(grid, batch, st)));
     prof_after(0, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
@@ -671,13 +762,20 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     float* csum = colsum_out;  // split partials live behind the product partials
     if (colsum_out && p.splits > 1) csum = scratch + (size_t)p.splits * ni * nj;
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
+    int gx = 0, gy = 0, gz = 0;
+    if (xcd_map_enabled()) {
+        gx = (int)grid.x;
+        gy = (int)grid.y;
+        gz = (int)grid.z;
+        grid = dim3(grid.x * grid.y * grid.z);
+    }
     prof_before(2, st);
     if (p.bm == 128)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum);
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum);
+                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz);
     prof_after(2, st);
     MARL_LAUNCH_CHECK();
     if (p.splits > 1) {
