@@ -449,6 +449,291 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
     return MARL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Fused layer backward: for rb patches per workgroup,
+//   dA_{l-1}[p][ci] = sum over taps, c of dZ_l[o(p, tap)][c] * W_l[c][tap][ci]
+// as 16x16x4 f32 MFMA tiles (the transposed convolution in gather form: input positions are
+// sorted by (row parity, column parity) so that a 16-row tile shares its set of valid taps and
+// the other taps are skipped), followed in LDS by the GroupNorm + SiLU backward of layer l-1.
+// Replaces the dCOLS GEMM, col2im and the GroupNorm-backward launch: dCOLS and dA never exist
+// in HBM.  (Backward of networks/vision.py:33-38 for Conv2d(3, stride 2, pad 1) + GroupNorm.)
+// ---------------------------------------------------------------------------
+constexpr int kDgradTiles = 4;  // row tiles per wave
+
+__device__ __forceinline__ float cnn_silu_grad(float y) {
+    const float s = 1.0f / (1.0f + expf(-y));
+    return s * (1.0f + y * (1.0f - s));
+}
+
+__global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Dz = lds;                    // [rb * P][cout + 4]
+    float* Zin = lds + A.off_zin;       // [rb * Pin][cin + 4]
+    float* Da = lds + A.off_da;         // [rb * Pin][cin + 4]   dA, then dZ in place
+    int* perm = reinterpret_cast<int*>(lds + A.off_perm);  // [MT * 16] lr << 16 | py << 8 | px, or -1
+    float* gstat = lds + A.off_stat;    // [rb * G][2]
+    float* gsum = lds + A.off_gsum;     // [nwaves][2][cpg]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int quad = lane >> 4, l16 = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * A.rb;
+    const int nrow = (int)(A.rows - row0 < A.rb ? A.rows - row0 : A.rb);
+    const int cin = A.cin, cout = A.cout, hin = A.hin, hout = A.hout, P = A.P, Pin = A.Pin, G = A.G;
+    const int zs = cout + 4, cs = cin + 4, cpg = (int)A.dcpg.d;
+
+    // ---- row order of the dA tiles: parity class major, then patch, then position
+    {
+        const int ne = (hin + 1) >> 1, no = hin >> 1;
+        int start = 0;
+        int cstart[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cstart[c] = start;
+            start += nrow * ((c >> 1) ? no : ne) * ((c & 1) ? no : ne);
+        }
+        cstart[4] = start;
+        for (int m = tid; m < A.MT * 16; m += nthreads) {
+            int v = -1;
+            if (m < cstart[4]) {
+                int c = 0;
+                if (m >= cstart[1]) c = 1;
+                if (m >= cstart[2]) c = 2;
+                if (m >= cstart[3]) c = 3;
+                const int ny = (c >> 1) ? no : ne, nx = (c & 1) ? no : ne;
+                const int idx = m - cstart[c];
+                const int lr = idx / (ny * nx), q = idx - lr * ny * nx;
+                const int yi = q / nx, xi = q - yi * nx;
+                v = (lr << 16) | ((2 * yi + (c >> 1)) << 8) | (2 * xi + (c & 1));
+            }
+            perm[m] = v;
+        }
+    }
+    // ---- dZ_l, Z_{l-1} and the statistics of this chunk -> LDS
+    {
+        const int M = nrow * P, c4 = cout >> 2;
+        const float* src = A.dz + row0 * P * (int64_t)cout;
+        for (int idx = tid; idx < M * c4; idx += nthreads) {
+            const int m = fdiv(idx, A.dc4o), k = (idx - m * c4) * 4;
+            *reinterpret_cast<float4*>(Dz + m * zs + k) = *reinterpret_cast<const float4*>(src + (int64_t)m * cout + k);
+        }
+        const int Mi = nrow * Pin, i4 = cin >> 2;
+        const float* zsrc = A.zin + row0 * Pin * (int64_t)cin;
+        for (int idx = tid; idx < Mi * i4; idx += nthreads) {
+            const int m = fdiv(idx, A.dc4i), k = (idx - m * i4) * 4;
+            *reinterpret_cast<float4*>(Zin + m * cs + k) = *reinterpret_cast<const float4*>(zsrc + (int64_t)m * cin + k);
+        }
+        for (int idx = tid; idx < nrow * G * 2; idx += nthreads) gstat[idx] = A.gst[row0 * G * 2 + idx];
+    }
+    __syncthreads();
+
+    // ---- transposed convolution: wave w owns column tile nt = w % NT and row tiles
+    // w / NT + i * (nwaves / NT); the accumulators stay in registers across the nine taps
+    {
+        const int NT = A.NT, wpn = nwaves / NT;
+        const int nt = wave % NT, wslot = wave / NT;
+        const bool wactive = wslot < wpn;  // nwaves need not be a multiple of NT
+        cf32x4 acc[kDgradTiles];
+        int rlr[kDgradTiles], rpy[kDgradTiles], rpx[kDgradTiles];
+#pragma unroll
+        for (int i = 0; i < kDgradTiles; ++i) {
+            acc[i] = cf32x4{0.f, 0.f, 0.f, 0.f};
+            const int mt = wslot + i * wpn;
+            const int pk = (wactive && mt < A.MT) ? perm[mt * 16 + l16] : -1;
+            rlr[i] = pk < 0 ? -1 : (pk >> 16);
+            rpy[i] = (pk >> 8) & 255;
+            rpx[i] = pk & 255;
+        }
+        int wr = nt * 16 + l16;
+        wr = wr < cin ? wr : cin - 1;
+        const int steps = (cout + 15) >> 4;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            int soff[kDgradTiles];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < kDgradTiles; ++i) {
+                const int ty = rpy[i] + 1 - kh, tx = rpx[i] + 1 - kw;
+                const bool ok = rlr[i] >= 0 && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) &&
+                                (ty >> 1) < hout && (tx >> 1) < hout;
+                soff[i] = ok ? (rlr[i] * P + (ty >> 1) * hout + (tx >> 1)) * zs + 4 * quad : -1;
+                any = any || ok;
+            }
+            if (!__any(any)) continue;  // wave-uniform: none of this wave's rows sees this tap
+            const float* wrow = A.wt + (int64_t)(tap * cin + wr) * A.ldwt + 4 * quad;
+            for (int st0 = 0; st0 < steps; st0 += 4) {
+                float4 bq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = (st0 + j) * 16;
+                    const bool ok = st0 + j < steps && kk + 4 * quad < cout;
+                    const float4 v = *reinterpret_cast<const float4*>(wrow + (ok ? kk : -4 * quad));
+                    bq[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < kDgradTiles; ++i) {
+                    if (!__any(soff[i] >= 0)) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (st0 + j < steps) {
+                            float4 a = *reinterpret_cast<const float4*>(Dz + (soff[i] >= 0 ? soff[i] + (st0 + j) * 16 : 4 * quad));
+                            if (soff[i] < 0 || (st0 + j) * 16 + 4 * quad >= cout) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[j].x, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[j].y, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[j].z, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[j].w, acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        const int n = nt * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < kDgradTiles; ++i) {
+            const int mt = wslot + i * wpn;
+            if (wactive && mt < A.MT && n < cin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pk = perm[mt * 16 + 4 * quad + r];
+                    if (pk >= 0)
+                        Da[((pk >> 16) * Pin + ((pk >> 8) & 255) * hin + (pk & 255)) * cs + n] = acc[i][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- GroupNorm + SiLU backward of layer l-1 on the LDS panels.  Wave w always works on
+    // group w % G (nwaves % G == 0), lane (cc, pslot) owns channel g * cpg + cc, so the affine
+    // partial sums have a single owner and a fixed order.
+    {
+        const int g = wave % G, wpg = nwaves / G;
+        const int cc = lane % cpg, pslot = lane / cpg, pstep = 64 / cpg;
+        const int c = g * cpg + cc;
+        const float gm = A.gamma[c], bt = A.beta[c];
+        const float inv_cnt = 1.0f / (float)(Pin * cpg);
+        float pg = 0.f, pb = 0.f;
+        for (int lr = wave / G; lr < nrow; lr += wpg) {
+            const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+            const float* zr = Zin + lr * Pin * cs + c;
+            float* dr = Da + lr * Pin * cs + c;
+            float s1 = 0.f, s2 = 0.f;
+            for (int pos = pslot; pos < Pin; pos += pstep) {
+                const float xh = (zr[pos * cs] - mean) * rstd;
+                const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
+                const float dxh = dy * gm;
+                s1 += dxh;
+                s2 += dxh * xh;
+                pg += dy * xh;
+                pb += dy;
+            }
+            const float m1 = wave_sum(s1) * inv_cnt, m2 = wave_sum(s2) * inv_cnt;
+            for (int pos = pslot; pos < Pin; pos += pstep) {
+                const float xh = (zr[pos * cs] - mean) * rstd;
+                const float dxh = dr[pos * cs] * cnn_silu_grad(gm * xh + bt) * gm;
+                dr[pos * cs] = rstd * (dxh - m1 - xh * m2);
+            }
+        }
+        for (int o = cpg; o < 64; o <<= 1) {
+            pg += __shfl_xor(pg, o);
+            pb += __shfl_xor(pb, o);
+        }
+        if (pslot == 0) {
+            gsum[(wave * 2) * cpg + cc] = pg;
+            gsum[(wave * 2 + 1) * cpg + cc] = pb;
+        }
+    }
+    __syncthreads();
+    // ---- dZ_{l-1} -> global (coalesced), affine partials of this workgroup
+    {
+        const int Mi = nrow * Pin, i4 = cin >> 2;
+        float* dst = A.dzin + row0 * Pin * (int64_t)cin;
+        for (int idx = tid; idx < Mi * i4; idx += nthreads) {
+            const int m = fdiv(idx, A.dc4i), k = (idx - m * i4) * 4;
+            *reinterpret_cast<float4*>(dst + (int64_t)m * cin + k) = *reinterpret_cast<const float4*>(Da + m * cs + k);
+        }
+        for (int e = tid; e < 2 * cin; e += nthreads) {
+            const int which = e >= cin, ch = e - which * cin;
+            const int g = fdiv(ch, A.dcpg), cc = ch - g * cpg;
+            float t = 0.f;
+            for (int w = g; w < nwaves; w += G) t += gsum[(w * 2 + which) * cpg + cc];
+            A.part[(size_t)blockIdx.x * 2 * cin + e] = t;
+        }
+    }
+}
+
+static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
+    a.rb = rb;
+    a.MT = (rb * a.Pin + 15) / 16;
+    a.NT = (a.cin + 15) / 16;
+    const int cpg = a.cin / a.G;
+    a.dc4o = make_fdiv(a.cout / 4);
+    a.dc4i = make_fdiv(a.cin / 4);
+    a.dPin = make_fdiv(a.Pin);
+    a.dcpg = make_fdiv(cpg);
+    a.dG = make_fdiv(a.G);
+    size_t off = ((size_t)rb * a.P * (a.cout + 4) + 3) & ~(size_t)3;
+    a.off_zin = (int)off;
+    off += ((size_t)rb * a.Pin * (a.cin + 4) + 3) & ~(size_t)3;
+    a.off_da = (int)off;
+    off += ((size_t)rb * a.Pin * (a.cin + 4) + 3) & ~(size_t)3;
+    a.off_perm = (int)off;
+    off += (size_t)a.MT * 16;
+    a.off_stat = (int)off;
+    off += (size_t)rb * a.G * 2;
+    a.off_gsum = (int)off;
+    off += (size_t)8 * 2 * cpg;
+    return off;
+}
+
+static int cnn_dgrad_rb(CnnDgradArgs& a) {
+    // largest rb <= 8 whose panels fit 72 KiB (two workgroups per CU) with at most
+    // kDgradTiles row tiles per wave, keeping >= 512 workgroups when the problem allows it
+    const int nt = (a.cin + 15) / 16;
+    const int wpn = 8 / nt;
+    if (wpn < 1) return 0;
+    for (int rb = 8; rb >= 1; --rb) {
+        if (cnn_dgrad_plan(a, rb) * sizeof(float) > 72 * 1024) continue;
+        if (a.MT > kDgradTiles * wpn) continue;
+        if (rb > 1 && cdiv(a.rows, rb) < 512) continue;
+        return rb;
+    }
+    return 0;
+}
+
+int cnn_dgrad_supported(const CnnDgradArgs& a0) {
+    if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
+    CnnDgradArgs a = a0;
+    if ((a.cin & 3) || (a.cout & 3) || a.cin % a.G != 0) return 0;
+    const int cpg = a.cin / a.G;
+    if (cpg > 64 || (cpg & (cpg - 1)) || 8 % a.G != 0) return 0;  // lane <-> channel ownership
+    if (a.hin > 255 || a.rows <= 0) return 0;
+    return cnn_dgrad_rb(a) > 0;
+}
+
+int cnn_dgrad_blocks(const CnnDgradArgs& a0) {
+    CnnDgradArgs a = a0;
+    const int rb = cnn_dgrad_rb(a);
+    return rb > 0 ? (int)cdiv(a.rows, rb) : 0;
+}
+
+int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
+    const int rb = cnn_dgrad_rb(a);
+    if (rb <= 0) {
+        set_error("fused CNN layer backward: shape outside its range");
+        return MARL_ELIMIT;
+    }
+    const size_t lds = cnn_dgrad_plan(a, rb) * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        raised = true;
+    }
+    hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
 // Environment.observe(): obs[r, c, y, x] = img[b, c, p0 + y, p1 + x]
 __global__ void patch_gather_kernel(const float* __restrict__ img, const int64_t* __restrict__ pos,
                                     float* __restrict__ obs, int64_t rows, int nb, int c, int H,

@@ -364,6 +364,28 @@ struct CnnFwdArgs {
 int cnn_fwd_supported(const CnnFwdArgs& a);
 int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// Fused CNN layer backward (cnn.hip): dZ_l -> [transposed conv] -> dA_{l-1} -> [GroupNorm +
+// SiLU backward of layer l-1] -> dZ_{l-1}, plus the per-workgroup dgamma / dbeta partials
+// ---------------------------------------------------------------------------
+struct CnnDgradArgs {
+    const float* dz;     // [rows * P][cout]      gradient of layer l's conv output
+    const float* wt;     // [9 * cin][ldwt]       layer l's weight, transposed (k = tap * cin + ci)
+    const float* zin;    // [rows * Pin][cin]     layer l-1's conv output (pre-norm)
+    const float* gst;    // [rows][G][2]          layer l-1's mean / rstd
+    const float *gamma, *beta;  // layer l-1's affine
+    float* dzin;         // [rows * Pin][cin]     out: gradient of layer l-1's conv output
+    float* part;         // [workgroups][2 * cin] out: dgamma | dbeta partial sums
+    int64_t rows;
+    int ldwt, cin, cout, hin, hout, P, Pin, G;
+    // filled by the launcher
+    int rb, MT, NT, off_zin, off_da, off_perm, off_stat, off_gsum;
+    FDiv dc4o, dc4i, dPin, dcpg, dG;
+};
+int cnn_dgrad_supported(const CnnDgradArgs& a);
+int cnn_dgrad_blocks(const CnnDgradArgs& a);
+int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st);
+
 int launch_gather_im2col(const void* img, int img_u8, const int32_t* pos, float* cols, int ldk,
                          int na, int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
 // same but from pre-gathered patches obs [R, c_img, f, f] (standalone step API)

@@ -349,6 +349,18 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_part(ln_bwd_blocks(r, d.n_mo), d.n_mo);
         upd_part(ln_bwd_blocks(r, d.n_m), d.n_m);
         for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr, d.ch[l + 1]), d.ch[l + 1]);
+        for (int l = 1; l < d.L; ++l) {  // fused layer backward: one partial row per workgroup
+            CnnDgradArgs g{};
+            g.rows = nr;
+            g.cin = d.ch[l];
+            g.cout = d.ch[l + 1];
+            g.hin = d.hw[l];
+            g.hout = d.hw[l + 1];
+            g.P = d.P[l];
+            g.Pin = d.P[l - 1];
+            g.G = d.grp[l - 1];
+            if (cnn_dgrad_supported(g)) upd_part(cnn_dgrad_blocks(g), d.ch[l]);
+        }
         int widths[] = {d.nC, d.nlb, d.nla, 4, d.nA, d.n_mo, d.nm2, d.n_m, 4 * d.n_b, 4 * d.n_a, d.n_d};
         for (int wv : widths) upd_cs(nr, wv);
         for (int l = 0; l < d.L; ++l) upd_cs(nr * d.P[l], d.ch[l + 1]);
@@ -1116,17 +1128,48 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         const float* da = c.at(c.e.DU);
         int64_t ldda = d.ld_nin;
         int chw = 1;
+        bool have_dz = false;  // DZ[l] already produced by the fused layer backward of layer l+1
         for (int l = d.L - 1; l >= 0; --l) {
             const int co = d.ch[l + 1];
             const int64_t rows = NR * d.P[l];
             float* dz = c.at(c.e.DZ[l]);
-            MARL_TRY(launch_gn_silu_bwd(da, ldda, chw, c.at(c.e.Z[l], 0), c.at(c.e.GST[l], 0),
-                                        c.wp(4 * l + 2), c.wp(4 * l + 3), dz, c.at(c.e.PART), NR,
-                                        d.P[l], co, d.grp[l], st));
-            MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR, co), co, grads[4 * l + 2],
-                                          grads[4 * l + 3], 0, st));
+            if (!have_dz) {
+                MARL_TRY(launch_gn_silu_bwd(da, ldda, chw, c.at(c.e.Z[l], 0), c.at(c.e.GST[l], 0),
+                                            c.wp(4 * l + 2), c.wp(4 * l + 3), dz, c.at(c.e.PART), NR,
+                                            d.P[l], co, d.grp[l], st));
+                MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR, co), co,
+                                              grads[4 * l + 2], grads[4 * l + 3], 0, st));
+            }
+            have_dz = false;
             MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
             if (l > 0) {
+                // dZ_l -> dZ_{l-1} in one launch (transposed conv + GroupNorm/SiLU backward)
+                CnnDgradArgs g{};
+                g.dz = dz;
+                g.wt = c.wt(4 * l);
+                g.ldwt = p4(co);
+                g.zin = c.at(c.e.Z[l - 1], 0);
+                g.gst = c.at(c.e.GST[l - 1], 0);
+                g.gamma = c.wp(4 * (l - 1) + 2);
+                g.beta = c.wp(4 * (l - 1) + 3);
+                g.dzin = c.at(c.e.DZ[l - 1]);
+                g.part = c.at(c.e.PART);
+                g.rows = NR;
+                g.cin = d.ch[l];
+                g.cout = co;
+                g.hin = d.hw[l];
+                g.hout = d.hw[l + 1];
+                g.P = d.P[l];
+                g.Pin = d.P[l - 1];
+                g.G = d.grp[l - 1];
+                if (cnn_dgrad_supported(g) &&
+                    (size_t)cnn_dgrad_blocks(g) * 2 * d.ch[l] <= c.e.part_floats) {
+                    MARL_TRY(launch_cnn_dgrad(g, st));
+                    MARL_TRY(launch_reduce_affine(c.at(c.e.PART), cnn_dgrad_blocks(g), d.ch[l],
+                                                  grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3], 0, st));
+                    have_dz = true;
+                    continue;
+                }
                 MARL_TRY(gemm1(c, gemm_prob(dz, co, c.wt(4 * l), p4(co), co, c.at(c.e.DCOLS[l]),
                                             d.ldk[l], (int)rows, d.K[l])));
                 MARL_TRY(launch_col2im(c.at(c.e.DCOLS[l]), d.ldk[l], c.at(c.e.DA[l - 1]), NR,

@@ -618,6 +618,13 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
         max_n = batch.p[i].n > max_n ? batch.p[i].n : max_n;
         blocks128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 128);
     }
+    static const bool log_shapes = getenv("MARL_GEMM_LOG") != nullptr;  // perf debugging aid
+    if (log_shapes)
+        for (int i = 0; i < batch.count; ++i)
+            fprintf(stderr, "[gemm_nt] %d/%d m=%d n=%d k=%d+%d acc=%d bias=%d lda=%d ldc=%d\n", i,
+                    batch.count, batch.p[i].m, batch.p[i].n, batch.p[i].seg[0].k,
+                    batch.p[i].nseg > 1 ? batch.p[i].seg[1].k : 0, batch.p[i].accumulate,
+                    batch.p[i].bias != nullptr, batch.p[i].seg[0].lda, batch.p[i].ldc);
     prof_before(1, st);
     if (blocks128 >= 256 && max_n >= 96) {
         const int g = gemm_groups();
@@ -761,6 +768,10 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     }
     float* csum = colsum_out;  // split partials live behind the product partials
     if (colsum_out && p.splits > 1) csum = scratch + (size_t)p.splits * ni * nj;
+    static const bool log_shapes = getenv("MARL_GEMM_LOG") != nullptr;
+    if (log_shapes)
+        fprintf(stderr, "[gemm_tn] ni=%d nj=%d rows=%lld bm=%d splits=%d colsum=%d\n", ni, nj,
+                (long long)rows, p.bm, p.splits, colsum_out != nullptr);
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
     int gx = 0, gy = 0, gz = 0;
     if (xcd_map_enabled()) {

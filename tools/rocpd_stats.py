@@ -80,5 +80,20 @@ def by_grid(path: str, pattern: str) -> None:
         print(f"{k} calls {a[0]} total_ms {a[1] / 1e6:.3f} avg_us {a[1] / a[0] / 1e3:.2f}")
 
 
-if __name__ == "__main__" and len(sys.argv) > 3:
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] != "--seq":
     by_grid(sys.argv[1], sys.argv[3])
+
+
+def sequence(path: str, pattern: str, last: int) -> None:
+    """durations (us) of the last `last` launches whose kernel name contains `pattern`, in launch order"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else "kernel_name"
+    rows = db.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    rows = [(short(n), (e - s) / 1e3) for n, s, e in rows if pattern in n][-last:]
+    for n, d in rows:
+        print(f"{d:9.2f}  {n}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 4 and sys.argv[3] == "--seq":
+    sequence(sys.argv[1], sys.argv[4], int(sys.argv[5]))
