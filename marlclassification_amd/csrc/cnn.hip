@@ -460,8 +460,9 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 constexpr int kDgradTiles = 4;  // row tiles per wave
 
+// v_exp_f32 / v_rcp_f32 based (~1e-7 relative error, inside the 1e-5 parity budget)
 __device__ __forceinline__ float cnn_silu_grad(float y) {
-    const float s = 1.0f / (1.0f + expf(-y));
+    const float s = __frcp_rn(1.0f + __expf(-y));
     return s * (1.0f + y * (1.0f - s));
 }
 
@@ -481,6 +482,10 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
     const int cin = A.cin, cout = A.cout, hin = A.hin, hout = A.hout, P = A.P, Pin = A.Pin, G = A.G;
     const int zs = cout + 4, cs = cin + 4, cpg = (int)A.dcpg.d;
 
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(A.ts);
+#endif
+    MARL_TS();
     // ---- row order of the dA tiles: parity class major, then patch, then position
     {
         const int ne = (hin + 1) >> 1, no = hin >> 1;
@@ -524,59 +529,80 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
         }
         for (int idx = tid; idx < nrow * G * 2; idx += nthreads) gstat[idx] = A.gst[row0 * G * 2 + idx];
     }
+    MARL_TS();
     __syncthreads();
+    MARL_TS();
 
-    // ---- transposed convolution: wave w owns column tile nt = w % NT and row tiles
-    // w / NT + i * (nwaves / NT); the accumulators stay in registers across the nine taps
+    // ---- transposed convolution: wave w owns column tile nt = w % NT and a CONTIGUOUS range of
+    // row tiles (same parity class -> same taps, so one weight fragment feeds all of them);
+    // the accumulators stay in registers across the nine taps
     {
         const int NT = A.NT, wpn = nwaves / NT;
         const int nt = wave % NT, wslot = wave / NT;
         const bool wactive = wslot < wpn;  // nwaves need not be a multiple of NT
+        // row-tile range of this wave slot (equal-cost split made by the launcher)
+        const int tb = wactive ? A.tbeg[wslot] : 0, tpw = wactive ? A.tbeg[wslot + 1] - tb : 0;
         cf32x4 acc[kDgradTiles];
-        int rlr[kDgradTiles], rpy[kDgradTiles], rpx[kDgradTiles];
+        // per row tile: this lane's row (patch base offset in Dz, input position) and the
+        // 9-bit set of taps that reach a valid output position; the wave-wide union of the
+        // sets is kept on the scalar unit so that skipped taps cost one scalar branch
+        int rbase[kDgradTiles], rpy[kDgradTiles], rpx[kDgradTiles], tmask[kDgradTiles];
+        unsigned wmask[kDgradTiles], wave_mask = 0;
 #pragma unroll
         for (int i = 0; i < kDgradTiles; ++i) {
             acc[i] = cf32x4{0.f, 0.f, 0.f, 0.f};
-            const int mt = wslot + i * wpn;
-            const int pk = (wactive && mt < A.MT) ? perm[mt * 16 + l16] : -1;
-            rlr[i] = pk < 0 ? -1 : (pk >> 16);
-            rpy[i] = (pk >> 8) & 255;
-            rpx[i] = pk & 255;
+            const int mt = tb + i;
+            const int pk = (wactive && i < tpw && mt < A.MT) ? perm[mt * 16 + l16] : -1;
+            const int py = (pk >> 8) & 255, px = pk & 255;
+            rbase[i] = (pk >> 16) * P * zs + 4 * quad;
+            rpy[i] = py;
+            rpx[i] = px;
+            int my = 0, mx = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ty = py + 1 - k, tx = px + 1 - k;
+                if (ty >= 0 && !(ty & 1) && (ty >> 1) < hout) my |= 1 << k;
+                if (tx >= 0 && !(tx & 1) && (tx >> 1) < hout) mx |= 1 << k;
+            }
+            int tm = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (my & (1 << k)) tm |= mx << (3 * k);
+            tmask[i] = pk < 0 ? 0 : tm;
+            unsigned wm_ = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (__ballot((tmask[i] >> t) & 1) != 0ull) wm_ |= 1u << t;
+            wmask[i] = wm_;
+            wave_mask |= wm_;
         }
         int wr = nt * 16 + l16;
         wr = wr < cin ? wr : cin - 1;
         const int steps = (cout + 15) >> 4;
+        const float* wbase = A.wt + (int64_t)wr * A.ldwt + 4 * quad;
+        const int64_t tap_stride = (int64_t)cin * A.ldwt;
         for (int tap = 0; tap < 9; ++tap) {
+            if (!((wave_mask >> tap) & 1u)) continue;  // none of this wave's rows sees this tap
             const int kh = tap / 3, kw = tap - 3 * kh;
-            int soff[kDgradTiles];
-            bool any = false;
-#pragma unroll
-            for (int i = 0; i < kDgradTiles; ++i) {
-                const int ty = rpy[i] + 1 - kh, tx = rpx[i] + 1 - kw;
-                const bool ok = rlr[i] >= 0 && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1) &&
-                                (ty >> 1) < hout && (tx >> 1) < hout;
-                soff[i] = ok ? (rlr[i] * P + (ty >> 1) * hout + (tx >> 1)) * zs + 4 * quad : -1;
-                any = any || ok;
-            }
-            if (!__any(any)) continue;  // wave-uniform: none of this wave's rows sees this tap
-            const float* wrow = A.wt + (int64_t)(tap * cin + wr) * A.ldwt + 4 * quad;
             for (int st0 = 0; st0 < steps; st0 += 4) {
                 float4 bq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int kk = (st0 + j) * 16;
                     const bool ok = st0 + j < steps && kk + 4 * quad < cout;
-                    const float4 v = *reinterpret_cast<const float4*>(wrow + (ok ? kk : -4 * quad));
+                    const float4 v = *reinterpret_cast<const float4*>(wbase + tap * tap_stride + (ok ? kk : -4 * quad));
                     bq[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int i = 0; i < kDgradTiles; ++i) {
-                    if (!__any(soff[i] >= 0)) continue;
+                    if (!((wmask[i] >> tap) & 1u)) continue;
+                    const bool valid = (tmask[i] >> tap) & 1;
+                    const int off = rbase[i] + (((rpy[i] + 1 - kh) >> 1) * hout + ((rpx[i] + 1 - kw) >> 1)) * zs;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (st0 + j < steps) {
-                            float4 a = *reinterpret_cast<const float4*>(Dz + (soff[i] >= 0 ? soff[i] + (st0 + j) * 16 : 4 * quad));
-                            if (soff[i] < 0 || (st0 + j) * 16 + 4 * quad >= cout) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                            float4 a = *reinterpret_cast<const float4*>(Dz + (valid ? off + (st0 + j) * 16 : 4 * quad));
+                            if (!valid || (st0 + j) * 16 + 4 * quad >= cout) a = make_float4(0.f, 0.f, 0.f, 0.f);
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[j].x, acc[i], 0, 0, 0);
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[j].y, acc[i], 0, 0, 0);
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[j].z, acc[i], 0, 0, 0);
@@ -586,11 +612,12 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
                 }
             }
         }
+        MARL_TS();
         const int n = nt * 16 + l16;
 #pragma unroll
         for (int i = 0; i < kDgradTiles; ++i) {
-            const int mt = wslot + i * wpn;
-            if (wactive && mt < A.MT && n < cin) {
+            const int mt = tb + i;
+            if (wactive && i < tpw && mt < A.MT && n < cin) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pk = perm[mt * 16 + 4 * quad + r];
@@ -600,7 +627,9 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
             }
         }
     }
+    MARL_TS();
     __syncthreads();
+    MARL_TS();
 
     // ---- GroupNorm + SiLU backward of layer l-1 on the LDS panels.  Wave w always works on
     // group w % G (nwaves % G == 0), lane (cc, pslot) owns channel g * cpg + cc, so the affine
@@ -612,11 +641,39 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
         const float gm = A.gamma[c], bt = A.beta[c];
         const float inv_cnt = 1.0f / (float)(Pin * cpg);
         float pg = 0.f, pb = 0.f;
+        constexpr int kKeep = 8;  // positions per lane kept in registers between the two passes
+        const bool keep = Pin <= kKeep * pstep;
         for (int lr = wave / G; lr < nrow; lr += wpg) {
             const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
             const float* zr = Zin + lr * Pin * cs + c;
             float* dr = Da + lr * Pin * cs + c;
             float s1 = 0.f, s2 = 0.f;
+            if (keep) {
+                float xk[kKeep], dk[kKeep];
+#pragma unroll
+                for (int u = 0; u < kKeep; ++u) {
+                    const int pos = pslot + u * pstep;
+                    xk[u] = dk[u] = 0.f;
+                    if (pos < Pin) {
+                        const float xh = (zr[pos * cs] - mean) * rstd;
+                        const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
+                        const float dxh = dy * gm;
+                        xk[u] = xh;
+                        dk[u] = dxh;
+                        s1 += dxh;
+                        s2 += dxh * xh;
+                        pg += dy * xh;
+                        pb += dy;
+                    }
+                }
+                const float m1 = wave_sum(s1) * inv_cnt, m2 = wave_sum(s2) * inv_cnt;
+#pragma unroll
+                for (int u = 0; u < kKeep; ++u) {
+                    const int pos = pslot + u * pstep;
+                    if (pos < Pin) dr[pos * cs] = rstd * (dk[u] - m1 - xk[u] * m2);
+                }
+                continue;
+            }
             for (int pos = pslot; pos < Pin; pos += pstep) {
                 const float xh = (zr[pos * cs] - mean) * rstd;
                 const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
@@ -642,7 +699,9 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
             gsum[(wave * 2 + 1) * cpg + cc] = pb;
         }
     }
+    MARL_TS();
     __syncthreads();
+    MARL_TS();
     // ---- dZ_{l-1} -> global (coalesced), affine partials of this workgroup
     {
         const int Mi = nrow * Pin, i4 = cin >> 2;
@@ -659,6 +718,7 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
             A.part[(size_t)blockIdx.x * 2 * cin + e] = t;
         }
     }
+    MARL_TS();
 }
 
 static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
@@ -682,6 +742,43 @@ static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
     off += (size_t)rb * a.G * 2;
     a.off_gsum = (int)off;
     off += (size_t)8 * 2 * cpg;
+    // Row tiles -> wave slots: contiguous ranges (one parity class -> one set of taps, so one
+    // weight fragment feeds every tile of a range) of about equal cost; a tile costs one unit
+    // plus one per tap of the classes it touches (1, 2, 2, 4 taps), <= kDgradTiles per slot.
+    {
+        const int ne = (a.hin + 1) / 2, no = a.hin / 2;
+        int cstart[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < 4; ++c) cstart[c + 1] = cstart[c] + rb * ((c >> 1) ? no : ne) * ((c & 1) ? no : ne);
+        const int wpn = 8 / a.NT > 0 ? 8 / a.NT : 1;
+        int cost[64], total = 0;
+        for (int t = 0; t < a.MT && t < 64; ++t) {
+            int cmax = 0;
+            for (int e = 0; e < 2; ++e) {
+                const int m = t * 16 + e * 15;
+                if (m >= cstart[4]) continue;
+                int c = 0;
+                while (c < 3 && m >= cstart[c + 1]) ++c;
+                const int k = ((c >> 1) + 1) * ((c & 1) + 1);
+                cmax = k > cmax ? k : cmax;
+            }
+            cost[t] = 1 + cmax;
+            total += cost[t];
+        }
+        int t = 0, done = 0;
+        for (int sl = 0; sl < wpn && sl < 16; ++sl) {
+            a.tbeg[sl] = t;
+            const int target = (total * (sl + 1) + wpn - 1) / wpn;
+            int cnt = 0;
+            while (t < a.MT && cnt < kDgradTiles &&
+                   (done + cost[t] / 2 < target || a.MT - t > (wpn - 1 - sl) * kDgradTiles)) {
+                done += cost[t];
+                ++t;
+                ++cnt;
+            }
+        }
+        for (int sl = wpn; sl <= 16; ++sl) a.tbeg[sl] = a.MT;
+        a.tbeg[wpn] = a.MT;
+    }
     return off;
 }
 
@@ -693,7 +790,7 @@ static int cnn_dgrad_rb(CnnDgradArgs& a) {
     if (wpn < 1) return 0;
     for (int rb = 8; rb >= 1; --rb) {
         if (cnn_dgrad_plan(a, rb) * sizeof(float) > 72 * 1024) continue;
-        if (a.MT > kDgradTiles * wpn) continue;
+        if (a.MT > kDgradTiles * wpn || a.MT > 64) continue;
         if (rb > 1 && cdiv(a.rows, rb) < 512) continue;
         return rb;
     }
@@ -729,8 +826,21 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         raised = true;
     }
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts = nullptr;
+    static int calls = 0;
+    const int rec = ts_begin(&d_ts, calls) || ts_begin(&d_ts, calls - 1);
+    ++calls;
+    a.ts = rec ? d_ts : nullptr;
+#endif
     hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
     MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec) {
+        fprintf(stderr, "[ts] dgrad rb %d lds %zu cin %d cout %d blocks %d\n", rb, lds, a.cin, a.cout, (int)cdiv(a.rows, rb));
+        ts_report("cnn_dgrad", d_ts, 8);
+    }
+#endif
     return MARL_OK;
 }
 

@@ -380,7 +380,11 @@ struct CnnDgradArgs {
     int ldwt, cin, cout, hin, hout, P, Pin, G;
     // filled by the launcher
     int rb, MT, NT, off_zin, off_da, off_perm, off_stat, off_gsum;
+    int tbeg[17];  // row-tile range of wave slot s: [tbeg[s], tbeg[s + 1])
     FDiv dc4o, dc4i, dPin, dcpg, dG;
+#ifdef MARL_KERNEL_TS
+    long long* ts;
+#endif
 };
 int cnn_dgrad_supported(const CnnDgradArgs& a);
 int cnn_dgrad_blocks(const CnnDgradArgs& a);
