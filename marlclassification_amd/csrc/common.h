@@ -131,6 +131,11 @@ int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float*
 // dz = d(loss)/d(z) from da = d(loss)/d(silu out); dgamma/dbeta partial sums are written
 // to part[nblk][2][n]; returns nblk through *nblk_out.
 int ln_bwd_blocks(int64_t m, int n);
+// dz = LayerNorm+SiLU backward of da[r][c] = sum_{j<kin} g[r][j] * bt[c][j], kin <= 4, n <= 384
+int launch_ln_silu_bwd_rank(const float* g, int ldg, int kin, const float* bt, int ldbt,
+                            const float* z, int ldz, const float* stats, const float* gamma,
+                            const float* beta, float* dz, int lddz, float* part, int64_t m, int n,
+                            hipStream_t st);
 int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
                        const float* gamma, const float* beta, float* dz, int lddz, float* part,
                        int64_t m, int n, hipStream_t st);

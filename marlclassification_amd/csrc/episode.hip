@@ -903,6 +903,17 @@ static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, co
                                 c.st);
 }
 
+// LayerNorm+SiLU backward of a hidden layer whose successor has only kin <= 4 outputs: the
+// incoming gradient g * W1 is formed inside the kernel instead of by a K = kin GEMM
+static int ln_bwd_rank(const Ctx& c, const float* g, int ldg, int kin, int w1, const float* z, int ldz,
+                       const float* stats, int pw, int pb, int64_t rows, int n, float* const* grads,
+                       float* dz, int lddz) {
+    MARL_TRY(launch_ln_silu_bwd_rank(g, ldg, kin, c.wt(w1), p4(kin), z, ldz, stats, c.wp(pw),
+                                     c.wp(pb), dz, lddz, c.at(c.e.PART), rows, n, c.st));
+    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], 0,
+                                c.st);
+}
+
 static int episode_backward(const Ctx& c, const float* g_preds, const float* g_logp,
                             const float* g_values, float* const* grads) {
     const Dims& d = c.d;
@@ -931,20 +942,32 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
         MARL_TRY(launch_copy2d(g_values, 1, c.at(c.e.DVAL), 4, NR, 1, st));
     else
         MARL_TRY(launch_fill(c.at(c.e.DVAL), NR * 4, 0.f, st));
-    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DVAL), 4, c.wt(MARL_P_CRI_W1), 4, 1, c.at(c.e.DAC1),
-                                d.ld_nla, (int)NR, d.nla)));
     MARL_TRY(tn(c, c.at(c.e.DVAL), 4, c.at(c.e.AC1), d.ld_nla, MARL_P_CRI_W1, 1, d.nla, NR, grads[MARL_P_CRI_B1]));
-    MARL_TRY(ln_bwd(c, c.at(c.e.DAC1), d.ld_nla, c.at(c.e.ZC1), d.ld_nla, c.at(c.e.STC1),
-                    MARL_P_CRI_LNW, MARL_P_CRI_LNB, NR, d.nla, grads, 0));
+    if (d.nla <= 384) {
+        MARL_TRY(ln_bwd_rank(c, c.at(c.e.DVAL), 4, 1, MARL_P_CRI_W1, c.at(c.e.ZC1), d.ld_nla,
+                             c.at(c.e.STC1), MARL_P_CRI_LNW, MARL_P_CRI_LNB, NR, d.nla, grads,
+                             c.at(c.e.DAC1), d.ld_nla));
+    } else {
+        MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DVAL), 4, c.wt(MARL_P_CRI_W1), 4, 1, c.at(c.e.DAC1),
+                                    d.ld_nla, (int)NR, d.nla)));
+        MARL_TRY(ln_bwd(c, c.at(c.e.DAC1), d.ld_nla, c.at(c.e.ZC1), d.ld_nla, c.at(c.e.STC1),
+                        MARL_P_CRI_LNW, MARL_P_CRI_LNB, NR, d.nla, grads, 0));
+    }
     MARL_TRY(tn(c, c.at(c.e.DAC1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_CRI_W0, d.nla, d.n_a, NR, grads[MARL_P_CRI_B0]));
     // policy head: logp = log softmax(logits)[a]  (networks/policy.py:12-16, core/agent.py:57-61)
     MARL_TRY(launch_policy_dlogits(g_logp, c.PROBSs(0), c.ACTs(0), c.at(c.e.DLOG), d.ld_nA, NR,
                                    d.nA, st));
-    MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DLOG), d.ld_nA, c.wt(MARL_P_POL_W1), p4(d.nA), d.nA,
-                                c.at(c.e.DAP1), d.ld_nla, (int)NR, d.nla)));
     MARL_TRY(tn(c, c.at(c.e.DLOG), d.ld_nA, c.at(c.e.AP1, 0), d.ld_nla, MARL_P_POL_W1, d.nA, d.nla, NR, grads[MARL_P_POL_B1]));
-    MARL_TRY(ln_bwd(c, c.at(c.e.DAP1), d.ld_nla, c.at(c.e.ZP1, 0), d.ld_nla, c.at(c.e.STP1, 0),
-                    MARL_P_POL_LNW, MARL_P_POL_LNB, NR, d.nla, grads, 0));
+    if (d.nA <= 4 && d.nla <= 384) {
+        MARL_TRY(ln_bwd_rank(c, c.at(c.e.DLOG), d.ld_nA, d.nA, MARL_P_POL_W1, c.at(c.e.ZP1, 0),
+                             d.ld_nla, c.at(c.e.STP1, 0), MARL_P_POL_LNW, MARL_P_POL_LNB, NR, d.nla,
+                             grads, c.at(c.e.DAP1), d.ld_nla));
+    } else {
+        MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.DLOG), d.ld_nA, c.wt(MARL_P_POL_W1), p4(d.nA), d.nA,
+                                    c.at(c.e.DAP1), d.ld_nla, (int)NR, d.nla)));
+        MARL_TRY(ln_bwd(c, c.at(c.e.DAP1), d.ld_nla, c.at(c.e.ZP1, 0), d.ld_nla, c.at(c.e.STP1, 0),
+                        MARL_P_POL_LNW, MARL_P_POL_LNB, NR, d.nla, grads, 0));
+    }
     MARL_TRY(tn(c, c.at(c.e.DAP1), d.ld_nla, c.HCs(1), d.ld_na, MARL_P_POL_W0, d.nla, d.n_a, NR, grads[MARL_P_POL_B0]));
     // gradients reaching h_t / h^_t from the heads, all steps at once
     {

@@ -139,6 +139,128 @@ __global__ __launch_bounds__(1024) void ln_silu_bwd_kernel(
     }
 }
 
+// Register-resident variant for widths <= 64 * U: z and da are read ONCE (the row lives in
+// registers between the statistics and the dz pass), the affine partial sums stay in registers
+// over the wave's rows.  With kin > 0 the incoming gradient is not read at all but formed on
+// the fly as da[r][c] = sum_{j < kin} g[r][j] * bt[c][j] (the layer above has only kin <= 4
+// outputs - critic value, policy logits - so its dX GEMM is a rank-kin update).
+template <int U>
+__global__ __launch_bounds__(1024) void ln_silu_bwd_reg_kernel(
+    const float* __restrict__ da, int ldda, const float* __restrict__ g, int ldg, int kin,
+    const float* __restrict__ bt, int ldbt, const float* __restrict__ z, int ldz,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dz, int lddz, float* __restrict__ part,
+    int64_t m, int n, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [waves][2][n]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    float gam[U], bet[U], pga[U], pgb[U], bw[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = lane + 64 * u;
+        gam[u] = c < n ? gamma[c] : 0.f;
+        bet[u] = c < n ? beta[c] : 0.f;
+        pga[u] = pgb[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bw[u][j] = (c < n && j < kin) ? bt[(size_t)c * ldbt + j] : 0.f;
+    }
+    const float inv_n = 1.0f / (float)n;
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = ((int64_t)blockIdx.x * nwaves + wave) * rpw + rr;
+        if (row >= m) break;
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        const float* zr = z + row * ldz;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < kin) gv[j] = g[row * ldg + j];
+        float xh[U], dxh[U];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * u;
+            xh[u] = dxh[u] = 0.f;
+            if (c < n) {
+                float dav;
+                if (kin > 0)
+                    dav = ((gv[0] * bw[u][0] + gv[1] * bw[u][1]) + gv[2] * bw[u][2]) + gv[3] * bw[u][3];
+                else
+                    dav = da[row * ldda + c];
+                xh[u] = (zr[c] - mean) * rstd;
+                const float dy = dav * silu_grad(gam[u] * xh[u] + bet[u]);
+                dxh[u] = dy * gam[u];
+                s1 += dxh[u];
+                s2 += dxh[u] * xh[u];
+                pga[u] += dy * xh[u];
+                pgb[u] += dy;
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+        float* dzr = dz + row * lddz;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * u;
+            if (c < n) dzr[c] = rstd * (dxh[u] - m1 - xh[u] * m2);
+        }
+    }
+    float* ga = sacc + (size_t)wave * 2 * n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = lane + 64 * u;
+        if (c < n) {
+            ga[c] = pga[u];
+            ga[n + c] = pgb[u];
+        }
+    }
+    __syncthreads();
+    float* p = part + (size_t)blockIdx.x * 2 * n;
+    for (int c = threadIdx.x; c < 2 * n; c += blockDim.x) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sacc[(size_t)w * 2 * n + c];
+        p[c] = t;
+    }
+}
+
+// da == nullptr: rank-kin source (g, bt), see the kernel
+static int launch_ln_silu_bwd_any(const float* da, int ldda, const float* g, int ldg, int kin,
+                                  const float* bt, int ldbt, const float* z, int ldz,
+                                  const float* stats, const float* gamma, const float* beta,
+                                  float* dz, int lddz, float* part, int64_t m, int n,
+                                  hipStream_t st) {
+    const int w = bwd_waves(n);
+    const int rpw = bwd_rows_per_wave(m, w);
+    const dim3 grid((unsigned)ln_bwd_blocks(m, n)), blk(64 * w);
+    const size_t lds = (size_t)w * 2 * n * sizeof(float);
+#define MARL_LN_REG(U_)                                                                         \
+    hipLaunchKernelGGL(ln_silu_bwd_reg_kernel<U_>, grid, blk, lds, st, da, ldda, g, ldg, kin, bt, \
+                       ldbt, z, ldz, stats, gamma, beta, dz, lddz, part, m, n, rpw)
+    if (n <= 64)
+        MARL_LN_REG(1);
+    else if (n <= 128)
+        MARL_LN_REG(2);
+    else if (n <= 256)
+        MARL_LN_REG(4);
+    else
+        MARL_LN_REG(6);
+#undef MARL_LN_REG
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+int launch_ln_silu_bwd_rank(const float* g, int ldg, int kin, const float* bt, int ldbt,
+                            const float* z, int ldz, const float* stats, const float* gamma,
+                            const float* beta, float* dz, int lddz, float* part, int64_t m, int n,
+                            hipStream_t st) {
+    if (m <= 0) return MARL_OK;
+    if (kin < 1 || kin > 4 || n > 384) {
+        set_error("rank-k LayerNorm backward: kin=%d n=%d outside its range", kin, n);
+        return MARL_ELIMIT;
+    }
+    return launch_ln_silu_bwd_any(nullptr, 0, g, ldg, kin, bt, ldbt, z, ldz, stats, gamma, beta, dz,
+                                  lddz, part, m, n, st);
+}
+
 int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
                        const float* gamma, const float* beta, float* dz, int lddz, float* part,
                        int64_t m, int n, hipStream_t st) {
@@ -147,6 +269,9 @@ int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const
         set_error("LayerNorm width %d > 2048 unsupported", n);
         return MARL_ELIMIT;
     }
+    if (n <= 384)
+        return launch_ln_silu_bwd_any(da, ldda, nullptr, 0, 0, nullptr, 0, z, ldz, stats, gamma, beta,
+                                      dz, lddz, part, m, n, st);
     const int w = bwd_waves(n);
     const int rpw = bwd_rows_per_wave(m, w);
     hipLaunchKernelGGL(ln_silu_bwd_kernel, dim3((unsigned)ln_bwd_blocks(m, n)), dim3(64 * w),
