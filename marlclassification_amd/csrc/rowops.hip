@@ -64,11 +64,60 @@ __global__ __launch_bounds__(256) void ln_silu_fwd_kernel(const float* __restric
     }
 }
 
+// widths <= 64 * U: the row is read once and stays in registers for both statistics passes
+template <int U>
+__global__ __launch_bounds__(256) void ln_silu_fwd_reg_kernel(const float* __restrict__ z, int ldz,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ out, int ldo,
+                                                              float* __restrict__ stats, int64_t m,
+                                                              int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float* zr = z + row * ldz;
+    float v[U];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = lane + 64 * u;
+        v[u] = c < n ? zr[c] : 0.f;
+        s += v[u];
+    }
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float d = (lane + 64 * u < n) ? v[u] - mean : 0.f;
+        v[u] = d;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + 1e-5f);
+    float* orow = out + row * ldo;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = lane + 64 * u;
+        if (c < n) orow[c] = silu_f(v[u] * rstd * gamma[c] + beta[c]);
+    }
+    if (stats && lane == 0) {
+        stats[row * 2] = mean;
+        stats[row * 2 + 1] = rstd;
+    }
+}
+
 int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
                        int ldo, float* stats, int64_t m, int n, hipStream_t st) {
     if (m <= 0) return MARL_OK;
-    hipLaunchKernelGGL(ln_silu_fwd_kernel, dim3((unsigned)cdiv(m, 4)), dim3(256), 0, st, z, ldz,
-                       gamma, beta, out, ldo, stats, m, n);
+    const dim3 grid((unsigned)cdiv(m, 4)), blk(256);
+    if (n <= 128)
+        hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<2>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
+                           stats, m, n);
+    else if (n <= 384)
+        hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<6>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
+                           stats, m, n);
+    else
+        hipLaunchKernelGGL(ln_silu_fwd_kernel, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo, stats,
+                           m, n);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
