@@ -298,6 +298,8 @@ struct PanelBwdLayer {
 struct PanelBwdProb {
     const float* da;  // d loss / d (SiLU output of layer[0]) [M, ldda]
     int ldda;
+    const float* da2;  // optional second addend of da [M, ldda2] (summed while staging)
+    int ldda2;
     int m, nlayers;
     PanelBwdLayer layer[2];
     float* dx;  // out: d loss / d (input of the first layer) [M, lddx]

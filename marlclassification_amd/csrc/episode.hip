@@ -1022,6 +1022,19 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                 gb.count = 2;
                 MARL_TRY(launch_gemm_nt(gb, c.st));
                 MARL_TRY(gemm1(cs, p));
+            } else if (panels && d.ld_nm2 >= d.ld_nmo) {
+                // four products of EQUAL depth (the two-segment one would run twice as long as
+                // the others and finish the launch alone): the action cell's share of d(decoded
+                // message) goes to this step's still unused dad1 rows and the decoder panel sums
+                // the two halves while staging
+                gb.p[2] = gemm_prob(c.at(c.e.GB, t), d.ld_gb,
+                                    c.wt(MARL_P_LB_WIH) + (size_t)d.nf * d.ld_gb, d.ld_gb, 4 * d.n_b,
+                                    ddbar, d.ld_nmo, R, d.n_mo);
+                gb.p[3] = gemm_prob(c.at(c.e.GA, t), d.ld_ga,
+                                    c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga, d.ld_ga, 4 * d.n_a,
+                                    c.at(c.e.DAD1) + (size_t)t * s_nm2, d.ld_nm2, R, d.n_mo);
+                gb.count = 4;
+                MARL_TRY(launch_gemm_nt(gb, c.st));
             } else {
                 gb.p[2] = p;
                 gb.count = 3;
@@ -1034,6 +1047,10 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             PanelBwdProb pd{};
             pd.da = ddbar;
             pd.ldda = d.ld_nmo;
+            if (!side && d.ld_nm2 >= d.ld_nmo) {
+                pd.da2 = dad1;
+                pd.ldda2 = d.ld_nm2;
+            }
             pd.m = R;
             pd.nlayers = 2;
             pd.layer[0] = PanelBwdLayer{c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),

@@ -404,7 +404,13 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             const int lr = e / c4, k = (e % c4) * 4;
             const int r = m0 + lr;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < P.m && k < n4) v = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
+            if (r < P.m && k < n4) {
+                v = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
+                if (P.da2) {
+                    const float4 w = *reinterpret_cast<const float4*>(P.da2 + (size_t)r * P.ldda2 + k);
+                    v = make_float4(v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w);
+                }
+            }
             *reinterpret_cast<float4*>(D + lr * ds + k) = v;
         }
     }
