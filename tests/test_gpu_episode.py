@@ -4,6 +4,8 @@ vectors generated from the real reference and against the CPU oracle.
 Tolerances (BASELINE.json north_star): agent positions and sampled action indices
 bit-exact; logits / log-probs / values within 1e-5 fp32; gradients within 1e-4 of the
 tensor's scale."""
+import os
+
 import pytest
 import torch as th
 
@@ -233,3 +235,21 @@ def test_other_baseline_configs_match_oracle(device, tag):
     free = eng.episode_forward(*args, None, False)
     nflip = (free.step_actions.cpu() != tr.step_actions).sum().item()
     assert nflip <= max(1, tr.step_actions.numel() // 2000), f"{nflip} sampled actions differ"
+
+
+@pytest.mark.parametrize("env", [{"MARL_CNN_FUSED": "0", "MARL_PANELS": "0"},
+                                 {"MARL_GEMM_GROUPS": "2", "MARL_XCD_MAP": "1"}])
+def test_alternative_kernel_paths_in_subprocess(device, env):
+    """The unfused CNN / LayerNorm-GEMM fallbacks (used for shapes outside the fused kernels'
+    range) and the opt-in GEMM schedules are selected by environment variables read once per
+    process, so the parity cases are re-run in a child process with them set."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child_env = dict(os.environ, **env)
+    r = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_episode.py"), "-x", "-q",
+         "-m", "gpu", "-k", "rollout_matches_reference or backward_and_adam or conftest"],
+        cwd=root, env=child_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
