@@ -124,7 +124,7 @@ __host__ __device__ inline int panel_ksplit(int K, int nt, int nwaves) {
 // ===========================================================================
 // forward
 // ===========================================================================
-__global__ __launch_bounds__(768) void panel_fwd_kernel(const PanelFwdBatch B) {
+__global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const PanelFwdProb& P = B.p[blockIdx.y];
     const int m0 = blockIdx.x * kPanelRows;
