@@ -17,7 +17,7 @@ namespace marl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;          // row depth of one staged tile of the TN kernel
+constexpr int BK = 32;          // row depth of one staged tile of the TN kernel
 
 
 // Gate non-linearities of the fused LSTM epilogue: v_exp_f32 / v_rcp_f32 based (~1e-7
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 // TN: contraction over rows.  LDS tiles are [BK rows][BM or BN columns]; the MFMA
 // fragments are ds_read_b32 with consecutive lanes on consecutive columns.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb,
                                                       float* __restrict__ out, int ldo,
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     constexpr int A_CH = BK * (BM / 4) / 256;
     constexpr int B_CH = BK * (BN / 4) / 256;
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BK * (BM + BN)]
 
     // gx > 0: 1-D launch, XCD-aware order (the tiles of one row slab run on one XCD, so its A
     // and B row panels come from that XCD's L2 for all but the first tile)
@@ -352,54 +352,68 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Staging coordinates of this thread's chunks: tile row kr, 4 columns at ic / jc (clamped
-    // into the padded width: columns past NI / NJ are never stored).  Loads are unconditional
-    // from clamped rows; rows past the split are zeroed on the A side at LDS-store time.
-    static_assert(A_CH == B_CH && A_CH <= 2, "square tiles");
-    int kr[A_CH];
-    const float* acol[A_CH];
-    const float* bcol[A_CH];
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        const int c = tid + 256 * i;
-        kr[i] = c / (BM / 4);
-        const int ic = i0 + (c % (BM / 4)) * 4;
-        const int jc = j0 + (c % (BN / 4)) * 4;
-        acol[i] = A + (ic < NI4 ? ic : NI4 - 4);
-        bcol[i] = B + (jc < NJ4 ? jc : NJ4 - 4);
+    // Staging: thread t moves chunks c = t + 256 * i: tile row c / (BM / 4), 4 columns at
+    // (c % (BM / 4)) * 4 (clamped into the padded width; columns past NI / NJ are never stored).
+    // Addresses are a UNIFORM base (row r_begin + tile * BK, advanced on the scalar unit) plus a
+    // fixed per-thread 32-bit byte offset; only the LAST tile of a split can reach past r_end:
+    // there the row is clamped and the A side zeroed at LDS-store time, all other tiles take
+    // the mask-free path.
+    static_assert(A_CH == B_CH && A_CH <= 4, "square tiles, at most 4 chunks per thread");
+    uint32_t aof0 = 0, aof1 = 0, aof2 = 0, aof3 = 0, bof0 = 0, bof1 = 0, bof2 = 0, bof3 = 0;
+#define MARL_TN_SET(idx_)                                                              \
+    if (A_CH > (idx_)) {                                                               \
+        const int c_ = tid + 256 * (idx_);                                             \
+        const int kr_ = c_ / (BM / 4);                                                 \
+        const int ic_ = i0 + (c_ % (BM / 4)) * 4, jc_ = j0 + (c_ % (BN / 4)) * 4;      \
+        aof##idx_ = ((uint32_t)kr_ * (uint32_t)lda + (uint32_t)(ic_ < NI4 ? ic_ : NI4 - 4)) * 4u; \
+        bof##idx_ = ((uint32_t)kr_ * (uint32_t)ldb + (uint32_t)(jc_ < NJ4 ? jc_ : NJ4 - 4)) * 4u; \
     }
-    float4 ra0, ra1, rb0, rb1;
-    float mk0 = 1.f, mk1 = 1.f;
+    MARL_TN_SET(0) MARL_TN_SET(1) MARL_TN_SET(2) MARL_TN_SET(3)
+#undef MARL_TN_SET
+    const char* abase = reinterpret_cast<const char*>(A + (size_t)r_begin * lda);
+    const char* bbase = reinterpret_cast<const char*>(B + (size_t)r_begin * ldb);
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    float mk0 = 1.f, mk1 = 1.f, mk2 = 1.f, mk3 = 1.f;
+    bool masked = false;  // uniform: the staged tile is the split's (partial) last tile
     // column sums of A (the bias gradient that goes with this weight gradient): taken for
     // free from the staged A tiles by the workgroups of the first column-tile
     const bool do_csum = csum != nullptr && by == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#define MARL_TN_LOAD1(idx_, clamp_)                                                    \
+    if (A_CH > (idx_)) {                                                               \
+        uint32_t da_ = 0u, db_ = 0u;                                                   \
+        if (clamp_) {                                                                  \
+            const int64_t gr_ = base_ + (tid + 256 * (idx_)) / (BM / 4);               \
+            const int64_t back_ = gr_ < r_end ? 0 : gr_ - (r_end - 1);                 \
+            da_ = (uint32_t)(-(back_ * lda * 4));                                      \
+            db_ = (uint32_t)(-(back_ * ldb * 4));                                      \
+            mk##idx_ = gr_ < r_end ? 1.f : 0.f;                                        \
+        }                                                                              \
+        ra##idx_ = *reinterpret_cast<const float4*>(abase + (aof##idx_ + da_));        \
+        rb##idx_ = *reinterpret_cast<const float4*>(bbase + (bof##idx_ + db_));        \
+    }
 #define MARL_TN_LOAD(tile_)                                                            \
     {                                                                                  \
         const int64_t base_ = r_begin + (int64_t)(tile_) * BK;                         \
-        {                                                                              \
-            const int64_t gr_ = base_ + kr[0];                                         \
-            const int64_t gc_ = gr_ < r_end ? gr_ : r_end - 1;                         \
-            ra0 = *reinterpret_cast<const float4*>(acol[0] + (size_t)gc_ * lda);       \
-            rb0 = *reinterpret_cast<const float4*>(bcol[0] + (size_t)gc_ * ldb);       \
-            mk0 = gr_ < r_end ? 1.f : 0.f;                                             \
+        masked = base_ + BK > r_end;                                                   \
+        if (!masked) {                                                                 \
+            MARL_TN_LOAD1(0, false) MARL_TN_LOAD1(1, false) MARL_TN_LOAD1(2, false) MARL_TN_LOAD1(3, false) \
+        } else {                                                                       \
+            MARL_TN_LOAD1(0, true) MARL_TN_LOAD1(1, true) MARL_TN_LOAD1(2, true) MARL_TN_LOAD1(3, true) \
         }                                                                              \
-        if (A_CH > 1) {                                                                \
-            const int64_t gr_ = base_ + kr[1 % A_CH];                                  \
-            const int64_t gc_ = gr_ < r_end ? gr_ : r_end - 1;                         \
-            ra1 = *reinterpret_cast<const float4*>(acol[1 % A_CH] + (size_t)gc_ * lda); \
-            rb1 = *reinterpret_cast<const float4*>(bcol[1 % A_CH] + (size_t)gc_ * ldb); \
-            mk1 = gr_ < r_end ? 1.f : 0.f;                                             \
-        }                                                                              \
+        abase += (size_t)BK * lda * 4;                                                 \
+        bbase += (size_t)BK * ldb * 4;                                                 \
     }
-#define MARL_TN_STORE(idx_, ra_, rb_, mk_)                                             \
+#define MARL_TN_STORE(idx_)                                                            \
     if (A_CH > (idx_)) {                                                               \
         const int c_ = tid + 256 * (idx_);                                             \
-        float4 v_ = ra_;                                                               \
-        v_.x *= mk_;                                                                   \
-        v_.y *= mk_;                                                                   \
-        v_.z *= mk_;                                                                   \
-        v_.w *= mk_;                                                                   \
+        float4 v_ = ra##idx_;                                                          \
+        if (masked) {                                                                  \
+            v_.x *= mk##idx_;                                                          \
+            v_.y *= mk##idx_;                                                          \
+            v_.z *= mk##idx_;                                                          \
+            v_.w *= mk##idx_;                                                          \
+        }                                                                              \
         if (do_csum) {                                                                 \
             cs.x += v_.x;                                                              \
             cs.y += v_.y;                                                              \
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             cs.w += v_.w;                                                              \
         }                                                                              \
         *reinterpret_cast<float4*>(As_ + (c_ / (BM / 4)) * BM + (c_ % (BM / 4)) * 4) = v_; \
-        *reinterpret_cast<float4*>(Bs_ + (c_ / (BN / 4)) * BN + (c_ % (BN / 4)) * 4) = rb_; \
+        *reinterpret_cast<float4*>(Bs_ + (c_ / (BN / 4)) * BN + (c_ % (BN / 4)) * 4) = rb##idx_; \
     }
 
     const int fcol = lane & 31;
@@ -418,10 +432,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         {
             float* As_ = smem + buf * BK * (BM + BN);
             float* Bs_ = As_ + BK * BM;
-            MARL_TN_STORE(0, ra0, rb0, mk0)
-            MARL_TN_STORE(1, ra1, rb1, mk1)
+            MARL_TN_STORE(0) MARL_TN_STORE(1) MARL_TN_STORE(2) MARL_TN_STORE(3)
         }
-        __syncthreads();
+        lds_barrier();
         if (tile + 1 < T) MARL_TN_LOAD(tile + 1)
         const float* As = smem + buf * BK * (BM + BN) + wm * (BM / WM) + fcol;
         const float* Bs = smem + buf * BK * (BM + BN) + BK * BM + wn * (BN / WN) + fcol;
@@ -439,6 +452,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+#undef MARL_TN_LOAD1
 #undef MARL_TN_LOAD
 #undef MARL_TN_STORE
 
@@ -781,12 +795,20 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         grid = dim3(grid.x * grid.y * grid.z);
     }
     prof_before(2, st);
-    if (p.bm == 128)
-        hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz);
+    static const int tbk = (getenv("MARL_TN_BK") && atoi(getenv("MARL_TN_BK")) == 16) ? 16 : 32;
+#define MARL_TN_LAUNCH(BM_, BK_)                                                               \
+    hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, 2, 2, BK_>), grid, dim3(256),                 \
+                       (size_t)2 * BK_ * 2 * BM_ * sizeof(float), st, a, lda, b, ldb, out, ldo, \
+                       stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz)
+    if (p.bm == 128 && tbk == 32)
+        MARL_TN_LAUNCH(128, 32);
+    else if (p.bm == 128)
+        MARL_TN_LAUNCH(128, 16);
+    else if (tbk == 32)
+        MARL_TN_LAUNCH(64, 32);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, a, lda, b, ldb,
-                           out, ldo, stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz);
+        MARL_TN_LAUNCH(64, 16);
+#undef MARL_TN_LAUNCH
     prof_after(2, st);
     MARL_LAUNCH_CHECK();
     if (p.splits > 1) {
