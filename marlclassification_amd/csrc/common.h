@@ -276,6 +276,10 @@ struct PanelFwdBatch {
     PanelFwdProb p[2];
     int count;
     int off_panel1, off_red, off_part, off_prm;  // LDS float offsets (filled by the launcher)
+    // optional (count == 1): extra workgroups behind the panel ones run the sampling kernel's
+    // rows (one wave per row) - an independent small kernel riding along in the same launch
+    int has_sample, panel_blocks;
+    SampleArgs sample;
 };
 int panel_supported(int k0, int n0, int n1);
 int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st);

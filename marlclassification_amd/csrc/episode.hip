@@ -539,7 +539,9 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
 }
 
 // message mean over the other agents + decoder -> U[t][:, nf:nf+n_mo]   (needs MSG[t])
-static int step_decode(const Ctx& c, int t) {
+// `sample` (panel path only): the sampling rows of the PREVIOUS step ride along in the same
+// launch (they are independent of the decoder); *fused reports whether that happened
+static int step_decode(const Ctx& c, int t, const SampleArgs* sample = nullptr, bool* fused = nullptr) {
     const Dims& d = c.d;
     const int R = (int)d.R;
     hipStream_t st = c.st;
@@ -564,6 +566,11 @@ static int step_decode(const Ctx& c, int t) {
                                 c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo,
                                 keep ? c.at(c.e.ZD2, t) : nullptr, d.ld_nmo,
                                 keep ? c.at(c.e.STD2, t) : nullptr, c.at(c.e.U, t) + d.nf, d.ld_nin};
+        if (sample) {
+            pb.has_sample = 1;
+            pb.sample = *sample;
+            if (fused) *fused = true;
+        }
         return launch_panel_fwd(pb, st);
     }
     MARL_TRY(launch_agg_msg(c.MSGs(t), c.at(c.e.MBAR, t), d.ld_nm, d.na, d.nb, d.n_m, st));
@@ -1345,12 +1352,13 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         MARL_TRY(g_side.init());
         c2.st = g_side.s;
     }
+    bool decoded_ahead = false;  // decoder(t) already ran with the sampling of step t-1
     for (int t = 0; t < d.ns; ++t) {
         MARL_TRY(step_cnn(c, t, in));
-        if (!side || t == 0)
-            MARL_TRY(step_decode(c, t));
-        else
+        if (side && t > 0)
             MARL_TRY(g_side.order(c2.st, c.st));  // decoder(t) ran on the side stream
+        else if (!decoded_ahead)
+            MARL_TRY(step_decode(c, t));
         MARL_TRY(step_pos_lstm(c, t, in, t > 0));  // lambda_t (t > 0) came from sample(t-1)
         if (side) {
             MARL_TRY(g_side.order(c.st, c2.st));  // side stream: after the LSTM of step t
@@ -1380,7 +1388,11 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
             a.pe_ldo = d.ld_nin;
             a.pe_nd = d.n_d;
         }
-        MARL_TRY(launch_sample(a, c.st));
+        // sample(t) and decoder(t+1) are independent (the decoder needs MSG[t+1], written by the
+        // encoder above): one launch runs both
+        decoded_ahead = false;
+        if (!side && t + 1 < d.ns) MARL_TRY(step_decode(c, t + 1, &a, &decoded_ahead));
+        if (!decoded_ahead) MARL_TRY(launch_sample(a, c.st));
     }
     if (side) MARL_TRY(g_side.order(c2.st, c.st));  // join before the caller's stream continues
     return heads_batched(c, 0, d.NR, step_values, step_preds);

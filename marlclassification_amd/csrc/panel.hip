@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "sample.h"
 
 namespace marl {
 
@@ -124,8 +125,18 @@ __host__ __device__ inline int panel_ksplit(int K, int nt, int nwaves) {
 // ===========================================================================
 // forward
 // ===========================================================================
+template <bool SAMPLE>
 __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (SAMPLE && (int)blockIdx.x >= B.panel_blocks) {
+        // ride-along sampling workgroup: one wave per row of the policy activations
+        const int r = ((int)blockIdx.x - B.panel_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        if (r >= B.sample.R) return;
+        float p[MARL_MAX_ACTIONS];
+        sample_row_logits(B.sample, r, p, threadIdx.x & 63);
+        sample_finish(B.sample, r, p, threadIdx.x & 63);
+        return;
+    }
     const PanelFwdProb& P = B.p[blockIdx.y];
     const int m0 = blockIdx.x * kPanelRows;
     if (m0 >= P.m) return;
@@ -358,13 +369,24 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
     }
     static bool raised = false;
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fwd_kernel),
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fwd_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kPanelMaxLds));
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fwd_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kPanelMaxLds));
         raised = true;
     }
-    hipLaunchKernelGGL(panel_fwd_kernel, dim3((unsigned)cdiv(mmax, kPanelRows), (unsigned)b.count),
-                       dim3(64 * waves), lds, st, b);
+    const unsigned pblocks = (unsigned)cdiv(mmax, kPanelRows);
+    if (b.has_sample && b.count == 1) {
+        b.panel_blocks = (int)pblocks;
+        const unsigned sblocks = (unsigned)cdiv(b.sample.R, waves);
+        hipLaunchKernelGGL(panel_fwd_kernel<true>, dim3(pblocks + sblocks, 1), dim3(64 * waves), lds, st, b);
+    } else {
+        b.has_sample = 0;
+        hipLaunchKernelGGL(panel_fwd_kernel<false>, dim3(pblocks, (unsigned)b.count), dim3(64 * waves),
+                           lds, st, b);
+    }
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

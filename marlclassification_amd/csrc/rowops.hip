@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "sample.h"
 
 namespace marl {
 
@@ -1004,135 +1005,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.R) return;
-    const float* ar = A.a_pol + (size_t)r * A.ld_a;
     float p[MARL_MAX_ACTIONS];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) p[j] = 0.f;
-    // logits: the activation row lives in registers (8 columns per lane per pass), the output
-    // layer's rows are read four actions at a time so that all loads of a group are in flight
-    for (int base = 0; base < A.nla; base += 512) {
-        float a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = base + lane + 64 * u;
-            a[u] = k < A.nla ? ar[k] : 0.f;
-        }
-#pragma unroll
-        for (int j0 = 0; j0 < MARL_MAX_ACTIONS; j0 += 4) {
-            if (j0 < A.nA) {
-                float wv[4][8];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = j0 + jj < A.nA ? j0 + jj : A.nA - 1;
-                    const float* wj = A.w1 + (size_t)j * A.ldw;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int k = base + lane + 64 * u;
-                        wv[jj][u] = k < A.nla ? wj[k] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) s += a[u] * wv[jj][u];
-                    p[j0 + jj] += s;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) {
-        if (j < A.nA) {
-            p[j] = wave_sum(p[j]) + A.b1[j];
-            mx = fmaxf(mx, p[j]);
-        } else {
-            p[j] = 0.f;
-        }
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
-        if (j < A.nA) {
-            p[j] = expf(p[j] - mx);
-            den += p[j];
-        }
-    int act = 0;
-    float best = -INFINITY, pa = 0.f;
-#pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
-        if (j < A.nA) {
-            p[j] = p[j] / den;
-            if (A.noise) {
-                const float sc = p[j] / A.noise[(size_t)r * A.nA + j];
-                if (sc > best) {
-                    best = sc;
-                    act = j;
-                }
-            }
-        }
-    if (!A.step_logp) {  // standalone step API: probabilities only
-        if (lane == 0)
-#pragma unroll
-            for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
-                if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
-        return;
-    }
-    if (A.forced) act = (int)A.forced[r];
-#pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
-        if (j == act) pa = p[j];
-    // every lane computes the move (wave-uniform), lane 0 stores it
-    const int pi0 = A.pos_in[r * 2], pi1 = A.pos_in[r * 2 + 1];
-    const int q0 = pi0 + A.table[act][0], q1 = pi1 + A.table[act][1];
-    const bool ok = q0 >= 0 && q0 + A.f < A.H && q1 >= 0 && q1 + A.f < A.W;
-    const int n0 = ok ? q0 : pi0, n1 = ok ? q1 : pi1;
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
-            if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
-        A.actions_i32[r] = act;
-        A.step_logp[r] = logf(pa);
-        A.pos_out[r * 2] = n0;
-        A.pos_out[r * 2 + 1] = n1;
-        if (A.step_pos) {
-            A.step_pos[(size_t)r * 2] = n0;
-            A.step_pos[(size_t)r * 2 + 1] = n1;
-        }
-        if (A.step_actions) A.step_actions[r] = act;
-    }
-    // position embedding of the NEXT step (networks/state.py:14-16 on pos / size), so that no
-    // separate launch sits between the move and the next LSTM
-    if (A.pe_W) {
-        const float p0 = (float)n0 / (float)A.H, p1 = (float)n1 / (float)A.W;
-        const int nd = A.pe_nd;
-        if (lane == 0 && A.pe_npos) {
-            A.pe_npos[(size_t)r * 4] = p0;
-            A.pe_npos[(size_t)r * 4 + 1] = p1;
-        }
-        float s = 0.f;
-        for (int j = lane; j < nd; j += 64) {
-            const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
-            A.pe_z[(size_t)r * A.pe_ldz + j] = v;
-            s += v;
-        }
-        const float mean = wave_sum(s) / (float)nd;
-        float q = 0.f;
-        for (int j = lane; j < nd; j += 64) {
-            const float dd = (A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1]) - mean;
-            q += dd * dd;
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)nd + 1e-5f);
-        if (lane == 0 && A.pe_stats) {
-            A.pe_stats[(size_t)r * 2] = mean;
-            A.pe_stats[(size_t)r * 2 + 1] = rstd;
-        }
-        for (int j = lane; j < nd; j += 64) {
-            const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
-            A.pe_out[(size_t)r * A.pe_ldo + j] = silu_f((v - mean) * rstd * A.pe_gamma[j] + A.pe_beta[j]);
-        }
-    }
+    sample_row_logits(A, r, p, lane);
+    sample_finish(A, r, p, lane);
 }
 
 int launch_sample(const SampleArgs& a, hipStream_t st) {
