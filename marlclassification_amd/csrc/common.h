@@ -284,6 +284,38 @@ struct PanelFwdBatch {
 int panel_supported(int k0, int n0, int n1);
 int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st);
 
+// LSTM cell backward (networks/recurrent.py:19-35 differentiated): gates holds the activated
+// i,f,g,o on entry and the pre-activation gradients on exit; dc holds dL/dc_t on entry and
+// dL/dc_{t-1} on exit.  One element (row, unit) per call.
+struct LstmBwdArgs {
+    const float* dh;
+    float* dc;
+    float* gates;
+    const float* c_prev;
+    const float* c_new;
+    int lddh, lddc, ldg, ldc, n;
+};
+struct LstmBwdBatch {
+    LstmBwdArgs a[2];
+    int64_t rows;
+};
+__device__ __forceinline__ void lstm_cell_bwd_elem(const LstmBwdArgs& A, int64_t rows, int64_t idx) {
+    const int n = A.n;
+    if (idx >= rows * n) return;
+    const int64_t r = idx / n;
+    const int u = (int)(idx % n);
+    float* g = A.gates + r * A.ldg + u;
+    const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
+    const float tc = tanhf(A.c_new[r * A.ldc + u]);
+    const float dhv = A.dh[r * A.lddh + u];
+    const float dcv = dhv * go * (1.0f - tc * tc) + A.dc[r * A.lddc + u];
+    g[0] = dcv * gg * gi * (1.0f - gi);
+    g[n] = dcv * A.c_prev[r * A.ldc + u] * gf * (1.0f - gf);
+    g[2 * n] = dcv * gi * (1.0f - gg * gg);
+    g[3 * n] = dhv * tc * go * (1.0f - go);
+    A.dc[r * A.lddc + u] = dcv * gf;
+}
+
 // backward of the same chain, layers listed from the LAST (output side) to the FIRST
 struct PanelBwdLayer {
     const float* z;  // saved pre-LayerNorm activations [M, ldz]
@@ -309,6 +341,11 @@ struct PanelBwdProb {
     float* dx;  // out: d loss / d (input of the first layer) [M, lddx]
     int lddx, accumulate;
     int off_e, off_prm, off_colp, off_part;  // LDS float offsets (filled by the launcher)
+    // optional: extra workgroups behind the panel ones run one LSTM cell's elementwise backward
+    // (an independent memory-bound kernel riding along with this latency-bound one)
+    int has_cell, panel_blocks;
+    LstmBwdArgs cell;
+    int64_t cell_rows;
 };
 int panel_bwd_blocks(int m);
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);

@@ -994,13 +994,23 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     const size_t s_nmo = (size_t)d.R * d.ld_nmo, s_nm2 = (size_t)d.R * d.ld_nm2,
                  s_nm = (size_t)d.R * d.ld_nm;
     const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
+    // The action cell's backward of step t-1 only needs dh^_t, which is complete after step t's
+    // W_hh product; it rides along (extra workgroups) with step t's decoder-panel launch, so
+    // that from the second iteration on only the belief cell is left for the separate launch.
+    const bool ride = panels && !use_side_stream();
+    bool action_done = false;  // the action cell of this step was handled by the ride-along
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
-        MARL_TRY(launch_lstm_cell_bwd2(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
-                                       d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.n_b,
-                                       c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
-                                       c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1), d.ld_na,
-                                       d.n_a, d.R, st));
+        if (action_done)
+            MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
+                                          d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.R, d.n_b, st));
+        else
+            MARL_TRY(launch_lstm_cell_bwd2(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb,
+                                           c.at(c.e.GB, t), d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb,
+                                           d.n_b, c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
+                                           c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1),
+                                           d.ld_na, d.n_a, d.R, st));
+        action_done = false;
         // The W_hh recurrent GEMM (main stream) and the decoder / encoder backward chain (side
         // stream) only meet at DH[t]: the chain's last kernel waits for the GEMM.
         const bool side = panels && use_side_stream();
@@ -1071,6 +1081,13 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             pd.dx = c.at(c.e.DMBAR);
             pd.lddx = d.ld_nm;
             pd.accumulate = 0;
+            if (ride && t > 0) {  // action cell of step t-1: gates GA[t-1], dh^ = DHC[t]
+                pd.has_cell = 1;
+                pd.cell = LstmBwdArgs{c.DHCs(t), c.at(c.e.DCC), c.at(c.e.GA, t - 1), c.CCs(t - 1),
+                                      c.CCs(t), d.ld_na, d.ld_na, d.ld_ga, d.ld_na, d.n_a};
+                pd.cell_rows = d.R;
+                action_done = true;
+            }
             MARL_TRY(launch_panel_bwd(pd, st));
             if (t > 0) {
                 float* dze2 = c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm;

@@ -397,8 +397,14 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
 // ===========================================================================
 constexpr int kBwdMaxCols = kPanelMaxCols;  // columns per lane in the row pass: widths up to 384
 
+template <bool CELL>
 __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (CELL && (int)blockIdx.x >= P.panel_blocks) {
+        lstm_cell_bwd_elem(P.cell, P.cell_rows,
+                           (int64_t)((int)blockIdx.x - P.panel_blocks) * blockDim.x + threadIdx.x);
+        return;
+    }
     const int m0 = blockIdx.x * kPanelRows;
     if (m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -594,13 +600,22 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     }
     static bool raised = false;
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_bwd_kernel),
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_bwd_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kPanelMaxLds));
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_bwd_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kPanelMaxLds));
         raised = true;
     }
-    hipLaunchKernelGGL(panel_bwd_kernel, dim3((unsigned)cdiv(p.m, kPanelRows)), dim3(64 * waves), lds,
-                       st, p);
+    const unsigned pblocks = (unsigned)cdiv(p.m, kPanelRows);
+    if (p.has_cell) {
+        p.panel_blocks = (int)pblocks;
+        const unsigned cblocks = (unsigned)cdiv(p.cell_rows * p.cell.n, 64 * waves);
+        hipLaunchKernelGGL(panel_bwd_kernel<true>, dim3(pblocks + cblocks), dim3(64 * waves), lds, st, p);
+    } else {
+        hipLaunchKernelGGL(panel_bwd_kernel<false>, dim3(pblocks), dim3(64 * waves), lds, st, p);
+    }
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

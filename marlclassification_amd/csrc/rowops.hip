@@ -936,36 +936,8 @@ int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w,
 // LSTM cell backward (pointwise part). gates holds activated i|f|g|o on entry and the
 // pre-activation gradients on exit; dc holds dL/dc_t on entry and dL/dc_{t-1} on exit.
 // ---------------------------------------------------------------------------
-struct LstmBwdArgs {
-    const float* dh;
-    float* dc;
-    float* gates;
-    const float* c_prev;
-    const float* c_new;
-    int lddh, lddc, ldg, ldc, n;
-};
-struct LstmBwdBatch {
-    LstmBwdArgs a[2];
-    int64_t rows;
-};
-
 __global__ void lstm_cell_bwd_kernel(const LstmBwdBatch B) {
-    const LstmBwdArgs& A = B.a[blockIdx.y];
-    const int n = A.n;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B.rows * n) return;
-    const int64_t r = idx / n;
-    const int u = (int)(idx % n);
-    float* g = A.gates + r * A.ldg + u;
-    const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
-    const float tc = tanhf(A.c_new[r * A.ldc + u]);
-    const float dhv = A.dh[r * A.lddh + u];
-    const float dcv = dhv * go * (1.0f - tc * tc) + A.dc[r * A.lddc + u];
-    g[0] = dcv * gg * gi * (1.0f - gi);
-    g[n] = dcv * A.c_prev[r * A.ldc + u] * gf * (1.0f - gf);
-    g[2 * n] = dcv * gi * (1.0f - gg * gg);
-    g[3 * n] = dhv * tc * go * (1.0f - go);
-    A.dc[r * A.lddc + u] = dcv * gf;
+    lstm_cell_bwd_elem(B.a[blockIdx.y], B.rows, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
