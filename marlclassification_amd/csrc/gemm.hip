@@ -738,7 +738,9 @@ struct TnPlan {
 
 static TnPlan tn_plan(int ni, int nj, int64_t rows) {
     TnPlan p;
-    p.bm = (ni >= 96 && nj >= 96) ? 128 : 64;
+    // 128-wide tiles only when there are enough of them: with < 4 tiles the 768-workgroup
+    // target turns into hundreds of row slabs and the slab reduction costs more than the product
+    p.bm = (ni >= 96 && nj >= 96 && cdiv(ni, 128) * cdiv(nj, 128) >= 4) ? 128 : 64;
     const int64_t tiles = cdiv(ni, p.bm) * cdiv(nj, p.bm);
     int64_t s = cdiv(768, tiles);
     const int64_t max_s = cdiv(rows, 4 * BK);  // at least 4 K tiles per split
