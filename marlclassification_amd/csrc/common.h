@@ -235,6 +235,9 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 // elementwise helpers
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
+// out[r][c] = a[r][c] + b[r][c]
+int launch_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                 int64_t rows, int cols, hipStream_t st);
 int launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
                   hipStream_t st);
 int launch_i64_to_i32(const int64_t* src, int32_t* dst, int64_t n, hipStream_t st);

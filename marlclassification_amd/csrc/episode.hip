@@ -41,6 +41,7 @@ struct Dims {
     int n_b, n_a, n_m, nm2, n_mo, n_d, nA, nC, nlb, nla;
     int ld_nin, ld_nb, ld_na, ld_nm, ld_nm2, ld_nmo, ld_nd, ld_nla, ld_nlb, ld_gb, ld_ga, ld_nC,
         ld_nA;
+    int ld_dbl;  // row stride of d(decoded message | position embedding): pad4(n_mo + n_d)
 };
 
 static int make_dims(const marl_config* c, Dims& d) {
@@ -114,6 +115,7 @@ static int make_dims(const marl_config* c, Dims& d) {
     d.ld_nm = p4(d.n_m);
     d.ld_nm2 = p4(d.nm2);
     d.ld_nmo = p4(d.n_mo);
+    d.ld_dbl = p4(d.n_mo + d.n_d);
     d.ld_nd = p4(d.n_d);
     d.ld_nla = p4(d.nla);
     d.ld_nlb = p4(d.nlb);
@@ -237,7 +239,7 @@ struct ELayout {
     // batched heads
     size_t ZC1, STC1, AC1, ZQ1, STQ1, AQ1;
     // backward only
-    size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DAD1, DMBAR, DZE2, DAE1, DU,
+    size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DDBAR2, DAD1, DMBAR, DZE2, DAE1, DU,
         DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
     size_t PART, CSUM, TNS, LOSS;
@@ -306,7 +308,8 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         e.DHC = b.take(S1 * R * d.ld_na);
         e.DC = b.take(R * d.ld_nb);
         e.DCC = b.take(R * d.ld_na);
-        e.DDBAR = b.take(NR * d.ld_nmo);
+        e.DDBAR = b.take(NR * d.ld_dbl);   // + the position-embedding columns of dU (belief cell)
+        e.DDBAR2 = b.take(NR * d.ld_dbl);  // the action cell's share of the same columns
         e.DAD1 = b.take(NR * d.ld_nm2);
         e.DMBAR = b.take(R * d.ld_nm);
         e.DZE2 = b.take(NR * d.ld_nm);
@@ -991,13 +994,14 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     MARL_TRY(launch_fill(c.at(c.e.DCC), d.R * d.ld_na, 0.f, st));
 
     // ---- reverse-time loop over the recurrent chain ----------------------------------
-    const size_t s_nmo = (size_t)d.R * d.ld_nmo, s_nm2 = (size_t)d.R * d.ld_nm2,
+    const size_t s_nmo = (size_t)d.R * d.ld_dbl, s_nm2 = (size_t)d.R * d.ld_nm2,
                  s_nm = (size_t)d.R * d.ld_nm;
     const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
     // The action cell's backward of step t-1 only needs dh^_t, which is complete after step t's
     // W_hh product; it rides along (extra workgroups) with step t's decoder-panel launch, so
     // that from the second iteration on only the belief cell is left for the separate launch.
     const bool ride = panels && !use_side_stream();
+    const bool dl_in_loop = ride;  // dU[:, nf:] (message + embedding columns) comes out of the loop
     bool action_done = false;  // the action cell of this step was handled by the ride-along
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
@@ -1032,24 +1036,26 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                                 c.DHCs(t), d.ld_na, R, d.n_a, nullptr, 1);
             GemmProb p = gemm_prob(c.at(c.e.GB, t), d.ld_gb,
                                    c.wt(MARL_P_LB_WIH) + (size_t)d.nf * d.ld_gb, d.ld_gb, 4 * d.n_b,
-                                   ddbar, d.ld_nmo, R, d.n_mo);
+                                   ddbar, d.ld_dbl, R, d.n_mo);
             gemm_add_seg(p, c.at(c.e.GA, t), d.ld_ga, c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga,
                          d.ld_ga, 4 * d.n_a);
             if (side) {  // W_hh products on the main stream, the message chain on the side stream
                 gb.count = 2;
                 MARL_TRY(launch_gemm_nt(gb, c.st));
                 MARL_TRY(gemm1(cs, p));
-            } else if (panels && d.ld_nm2 >= d.ld_nmo) {
-                // four products of EQUAL depth (the two-segment one would run twice as long as
-                // the others and finish the launch alone): the action cell's share of d(decoded
-                // message) goes to this step's still unused dad1 rows and the decoder panel sums
-                // the two halves while staging
+            } else if (dl_in_loop) {
+                // four products of EQUAL depth (a two-segment one would run twice as long as the
+                // others and finish the launch alone): each cell's share of dU[:, nf:] - the
+                // decoded-message AND the position-embedding columns, which sit next to each
+                // other and fit the same two 64-wide tiles - goes to its own buffer; the decoder
+                // panel sums the message halves while staging, the embedding halves are summed
+                // once after the loop.  The big dU product then only covers the CNN features.
                 gb.p[2] = gemm_prob(c.at(c.e.GB, t), d.ld_gb,
                                     c.wt(MARL_P_LB_WIH) + (size_t)d.nf * d.ld_gb, d.ld_gb, 4 * d.n_b,
-                                    ddbar, d.ld_nmo, R, d.n_mo);
+                                    ddbar, d.ld_dbl, R, d.n_mo + d.n_d);
                 gb.p[3] = gemm_prob(c.at(c.e.GA, t), d.ld_ga,
                                     c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga, d.ld_ga, 4 * d.n_a,
-                                    c.at(c.e.DAD1) + (size_t)t * s_nm2, d.ld_nm2, R, d.n_mo);
+                                    c.at(c.e.DDBAR2) + (size_t)t * s_nmo, d.ld_dbl, R, d.n_mo + d.n_d);
                 gb.count = 4;
                 MARL_TRY(launch_gemm_nt(gb, c.st));
             } else {
@@ -1063,16 +1069,16 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             const size_t pblk = (size_t)panel_bwd_blocks(R) * 2;
             PanelBwdProb pd{};
             pd.da = ddbar;
-            pd.ldda = d.ld_nmo;
-            if (!side && d.ld_nm2 >= d.ld_nmo) {
-                pd.da2 = dad1;
-                pd.ldda2 = d.ld_nm2;
+            pd.ldda = d.ld_dbl;
+            if (dl_in_loop) {
+                pd.da2 = c.at(c.e.DDBAR2) + (size_t)t * s_nmo;
+                pd.ldda2 = d.ld_dbl;
             }
             pd.m = R;
             pd.nlayers = 2;
             pd.layer[0] = PanelBwdLayer{c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
                                         c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo, ddbar,
-                                        d.ld_nmo, c.at(c.e.PLN[0]) + (size_t)t * pblk * d.n_mo,
+                                        d.ld_dbl, c.at(c.e.PLN[0]) + (size_t)t * pblk * d.n_mo,
                                         c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.nm2};
             pd.layer[1] = PanelBwdLayer{c.at(c.e.ZD1, t), d.ld_nm2, c.at(c.e.STD1, t),
                                         c.wp(MARL_P_DEC_LN0W), c.wp(MARL_P_DEC_LN0B), d.nm2, dad1,
@@ -1117,9 +1123,9 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             if (side) MARL_TRY(g_side.order(cs.st, c.st));  // join before step t-1
             continue;
         }
-        MARL_TRY(ln_bwd(c, ddbar, d.ld_nmo, c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
+        MARL_TRY(ln_bwd(c, ddbar, d.ld_dbl, c.at(c.e.ZD2, t), d.ld_nmo, c.at(c.e.STD2, t),
                         MARL_P_DEC_LN1W, MARL_P_DEC_LN1B, d.R, d.n_mo, grads, !first));
-        MARL_TRY(gemm1(c, gemm_prob(ddbar, d.ld_nmo, c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.n_mo, dad1,
+        MARL_TRY(gemm1(c, gemm_prob(ddbar, d.ld_dbl, c.wt(MARL_P_DEC_W1), p4(d.n_mo), d.n_mo, dad1,
                                     d.ld_nm2, R, d.nm2)));
         MARL_TRY(ln_bwd(c, dad1, d.ld_nm2, c.at(c.e.ZD1, t), d.ld_nm2, c.at(c.e.STD1, t),
                         MARL_P_DEC_LN0W, MARL_P_DEC_LN0B, d.R, d.nm2, grads, !first));
@@ -1157,7 +1163,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
     }
 
     // ---- weight gradients of the recurrent chain: one contraction over all steps -------
-    MARL_TRY(tn(c, c.at(c.e.DDBAR), d.ld_nmo, c.at(c.e.AD1, 0), d.ld_nm2, MARL_P_DEC_W1, d.n_mo, d.nm2, NR, grads[MARL_P_DEC_B1]));
+    MARL_TRY(tn(c, c.at(c.e.DDBAR), d.ld_dbl, c.at(c.e.AD1, 0), d.ld_nm2, MARL_P_DEC_W1, d.n_mo, d.nm2, NR, grads[MARL_P_DEC_B1]));
     MARL_TRY(tn(c, c.at(c.e.DAD1), d.ld_nm2, c.at(c.e.MBAR, 0), d.ld_nm, MARL_P_DEC_W0, d.nm2, d.n_m, NR, grads[MARL_P_DEC_B0]));
     if (ns > 1) {
         const int64_t er = (int64_t)(ns - 1) * d.R;  // the last step's message is never read
@@ -1179,10 +1185,14 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
 
     // ---- dU for all steps, then position embedding and CNN backward -------------------
     {
+        // with the [nf, nin) columns already produced step by step, only the CNN features remain
         GemmProb p = gemm_prob(c.at(c.e.GB, 0), d.ld_gb, c.wt(MARL_P_LB_WIH), d.ld_gb, 4 * d.n_b,
-                               c.at(c.e.DU), d.ld_nin, (int)NR, d.nin);
+                               c.at(c.e.DU), d.ld_nin, (int)NR, dl_in_loop ? d.nf : d.nin);
         gemm_add_seg(p, c.at(c.e.GA, 0), d.ld_ga, c.wt(MARL_P_LA_WIH), d.ld_ga, 4 * d.n_a);
         MARL_TRY(gemm1(c, p));
+        if (dl_in_loop)  // d(position embedding) = belief share + action share
+            MARL_TRY(launch_add2d(c.at(c.e.DDBAR) + d.n_mo, d.ld_dbl, c.at(c.e.DDBAR2) + d.n_mo, d.ld_dbl,
+                                  c.at(c.e.DU) + d.nf + d.n_mo, d.ld_nin, NR, d.n_d, st));
     }
     MARL_TRY(ln_bwd(c, c.at(c.e.DU) + d.nf + d.n_mo, d.ld_nin, c.at(c.e.ZPOS, 0), d.ld_nd,
                     c.at(c.e.STPOS, 0), MARL_P_POS_LNW, MARL_P_POS_LNB, NR, d.n_d, grads, 0,

@@ -1080,6 +1080,23 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds, float*
         dst[r * ldd + c] = src[r * lds + c];
     }
 }
+__global__ void add2d_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                             int64_t ldb, float* __restrict__ out, int64_t ldo, int64_t rows, int cols) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int64_t r = idx / cols;
+    const int c = (int)(idx % cols);
+    out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+}
+int launch_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                 int64_t rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return MARL_OK;
+    hipLaunchKernelGGL(add2d_kernel, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, st, a, lda, b,
+                       ldb, out, ldo, rows, cols);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
 int launch_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols,
                   hipStream_t st) {
     if (rows <= 0 || cols <= 0) return MARL_OK;
