@@ -126,8 +126,12 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
 // ---------------------------------------------------------------------------
 // row-wise kernels (rowops.hip)
 // ---------------------------------------------------------------------------
+// optional wdot / bdot / dot_out (n <= 384): dot_out[r] = out[r] . wdot + bdot[0] (a one-output
+// layer on top of the activation)
 int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
-                       int ldo, float* stats, int64_t m, int n, hipStream_t st);
+                       int ldo, float* stats, int64_t m, int n, hipStream_t st,
+                       const float* wdot = nullptr, const float* bdot = nullptr,
+                       float* dot_out = nullptr);
 // dz = d(loss)/d(z) from da = d(loss)/d(silu out); dgamma/dbeta partial sums are written
 // to part[nblk][2][n]; returns nblk through *nblk_out.
 int ln_bwd_blocks(int64_t m, int n);

@@ -753,12 +753,15 @@ static int heads_batched(const Ctx& c, int t0, int64_t rows, float* values, floa
                              c.at(c.e.ZC1), d.ld_nla, (int)rows, d.nla, c.wp(MARL_P_CRI_B0)),
                    gemm_prob(c.Hs(t0 + 1), d.ld_nb, c.wp(MARL_P_PRE_W0), d.ld_nb, d.n_b,
                              c.at(c.e.ZQ1), d.ld_nlb, (int)rows, d.nlb, c.wp(MARL_P_PRE_B0))));
+    const bool vdot = d.nla <= 384;  // the critic's output layer rides in the LayerNorm kernel
     MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZC1), d.ld_nla, c.wp(MARL_P_CRI_LNW), c.wp(MARL_P_CRI_LNB),
-                                c.at(c.e.AC1), d.ld_nla, c.at(c.e.STC1), rows, d.nla, st));
+                                c.at(c.e.AC1), d.ld_nla, c.at(c.e.STC1), rows, d.nla, st,
+                                vdot ? c.wp(MARL_P_CRI_W1) : nullptr, c.wp(MARL_P_CRI_B1), values));
     MARL_TRY(launch_ln_silu_fwd(c.at(c.e.ZQ1), d.ld_nlb, c.wp(MARL_P_PRE_LNW), c.wp(MARL_P_PRE_LNB),
                                 c.at(c.e.AQ1), d.ld_nlb, c.at(c.e.STQ1), rows, d.nlb, st));
-    MARL_TRY(launch_rowdot(c.at(c.e.AC1), d.ld_nla, c.wp(MARL_P_CRI_W1), c.wp(MARL_P_CRI_B1),
-                           values, rows, d.nla, st));
+    if (!vdot)
+        MARL_TRY(launch_rowdot(c.at(c.e.AC1), d.ld_nla, c.wp(MARL_P_CRI_W1), c.wp(MARL_P_CRI_B1),
+                               values, rows, d.nla, st));
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.AQ1), d.ld_nlb, c.wp(MARL_P_PRE_W1), d.ld_nlb, d.nlb,
                                 preds, d.nC, (int)rows, d.nC, c.wp(MARL_P_PRE_B1))));
     return MARL_OK;

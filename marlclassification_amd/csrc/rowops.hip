@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void ln_silu_fwd_reg_kernel(const float* __res
                                                               const float* __restrict__ beta,
                                                               float* __restrict__ out, int ldo,
                                                               float* __restrict__ stats, int64_t m,
-                                                              int n) {
+                                                              int n, const float* __restrict__ wdot,
+                                                              const float* __restrict__ bdot,
+                                                              float* __restrict__ dot_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -95,27 +97,41 @@ __global__ __launch_bounds__(256) void ln_silu_fwd_reg_kernel(const float* __res
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + 1e-5f);
     float* orow = out + row * ldo;
+    float dot = 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = lane + 64 * u;
-        if (c < n) orow[c] = silu_f(v[u] * rstd * gamma[c] + beta[c]);
+        if (c < n) {
+            const float a = silu_f(v[u] * rstd * gamma[c] + beta[c]);
+            orow[c] = a;
+            if (wdot) dot += a * wdot[c];
+        }
     }
     if (stats && lane == 0) {
         stats[row * 2] = mean;
         stats[row * 2 + 1] = rstd;
     }
+    if (wdot) {  // a one-output layer on top (critic value) comes for free from the registers
+        dot = wave_sum(dot);
+        if (lane == 0) dot_out[row] = dot + bdot[0];
+    }
 }
 
 int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
-                       int ldo, float* stats, int64_t m, int n, hipStream_t st) {
+                       int ldo, float* stats, int64_t m, int n, hipStream_t st, const float* wdot,
+                       const float* bdot, float* dot_out) {
     if (m <= 0) return MARL_OK;
     const dim3 grid((unsigned)cdiv(m, 4)), blk(256);
+    if (wdot && n > 384) {
+        set_error("fused row dot needs a LayerNorm width <= 384");
+        return MARL_ELIMIT;
+    }
     if (n <= 128)
         hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<2>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
-                           stats, m, n);
+                           stats, m, n, wdot, bdot, dot_out);
     else if (n <= 384)
         hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<6>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
-                           stats, m, n);
+                           stats, m, n, wdot, bdot, dot_out);
     else
         hipLaunchKernelGGL(ln_silu_fwd_kernel, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo, stats,
                            m, n);
