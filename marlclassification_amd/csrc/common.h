@@ -143,16 +143,9 @@ int launch_ln_silu_bwd_rank(const float* g, int ldg, int kin, const float* bt, i
 int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const float* stats,
                        const float* gamma, const float* beta, float* dz, int lddz, float* part,
                        int64_t m, int n, hipStream_t st);
-// out[n] (+)= sum over p of part[p][n]   (fixed order -> deterministic)
-int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, float* out, int n,
-                           int accumulate, hipStream_t st);
 // LayerNorm/GroupNorm partials [nparts][2][n] -> dgamma[n], dbeta[n]
 int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
                          int accumulate, hipStream_t st);
-// out[n] = sum over rows of x[r][n]; scratch holds colsum_blocks(rows) * n floats
-int colsum_blocks(int64_t rows);
-int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float* scratch,
-                  hipStream_t st);
 
 // GroupNorm + SiLU over NHWC rows: z [rows, P, C] -> a.  out_chw != 0 writes element
 // (pos, c) at out[row * ldo + c * P + pos] (reference Flatten order), else NHWC with ldo = P*C.
@@ -251,9 +244,6 @@ int launch_policy_dlogits(const float* dlogp, const float* probs, const int32_t*
 // values[r] = dot(a[r,:n], w[:n]) + b
 int launch_rowdot(const float* a, int lda, const float* w, const float* b, float* out,
                   int64_t rows, int n, hipStream_t st);
-// softmax rows in place helper for the standalone step API
-int launch_softmax_rows(const float* logits, int ld, float* probs, int64_t rows, int n,
-                        hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // row-panel MLP kernels (panel.hip)

@@ -242,8 +242,8 @@ struct ELayout {
     size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DDBAR2, DAD1, DMBAR, DZE2, DAE1, DU,
         DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
-    size_t PART, CSUM, TNS, LOSS;
-    size_t part_floats, csum_floats, tns_bytes, loss_floats;
+    size_t PART, TNS, LOSS;
+    size_t part_floats, tns_bytes, loss_floats;
     size_t total;
 };
 
@@ -296,7 +296,7 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
     e.ZQ1 = b.take(NR * d.ld_nlb);
     e.STQ1 = b.take(NR * 2);
     e.AQ1 = b.take(NR * d.ld_nlb);
-    e.part_floats = e.csum_floats = e.tns_bytes = e.loss_floats = 0;
+    e.part_floats = e.tns_bytes = e.loss_floats = 0;
     if (train) {
         e.GPRED = b.take(NR * d.ld_nC);
         e.DLOG = b.take(NR * d.ld_nA);
@@ -331,14 +331,10 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
             e.DA[l] = (l + 1 < d.L) ? b.take(NR * d.P[l] * d.ch[l + 1]) : 0;
         }
         // scratch sizes: maxima over every use
-        size_t part = 0, csum = 0, tns = 0;
+        size_t part = 0, tns = 0;
         auto upd_part = [&](int64_t blocks, int n) {
             const size_t v = (size_t)blocks * 2 * n;
             part = v > part ? v : part;
-        };
-        auto upd_cs = [&](int64_t rows, int n) {
-            const size_t v = (size_t)colsum_blocks(rows) * n;
-            csum = v > csum ? v : csum;
         };
         auto upd_tn = [&](int ni, int nj, int64_t rows) {
             const size_t v = gemm_tn_scratch_bytes(ni, nj, rows);
@@ -364,9 +360,6 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
             g.G = d.grp[l - 1];
             if (cnn_dgrad_supported(g)) upd_part(cnn_dgrad_blocks(g), d.ch[l]);
         }
-        int widths[] = {d.nC, d.nlb, d.nla, 4, d.nA, d.n_mo, d.nm2, d.n_m, 4 * d.n_b, 4 * d.n_a, d.n_d};
-        for (int wv : widths) upd_cs(nr, wv);
-        for (int l = 0; l < d.L; ++l) upd_cs(nr * d.P[l], d.ch[l + 1]);
         upd_tn(d.nC, d.nlb, nr);
         upd_tn(d.nlb, d.n_b, nr);
         upd_tn(1, d.nla, nr);
@@ -383,10 +376,8 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_tn(d.n_d, 2, nr);
         for (int l = 0; l < d.L; ++l) upd_tn(d.ch[l + 1], d.K[l], nr * d.P[l]);
         e.part_floats = part;
-        e.csum_floats = csum;
         e.tns_bytes = tns;
         e.PART = b.take(part);
-        e.CSUM = b.take(csum);
         e.TNS = b.take(tns / sizeof(float) + 16);
     }
     e.loss_floats = loss_scratch_floats(d.ns, d.na, d.nb);
@@ -898,9 +889,6 @@ static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, in
               int nj, int64_t rows, float* bias = nullptr) {
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
                           c.e.tns_bytes, c.st, bias);
-}
-static int csum(const Ctx& c, const float* x, int ld, int64_t rows, int n, float* out) {
-    return launch_colsum(x, ld, rows, n, out, c.at(c.e.CSUM), c.st);
 }
 // LayerNorm+SiLU backward in place (da -> dz) with affine gradients (accumulated when acc)
 static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, const float* stats,

@@ -347,46 +347,6 @@ int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const
     return MARL_OK;
 }
 
-// out[c] (+)= sum_p part[p * stride + c]; 64 columns x 4 interleaved part groups per block,
-// groups combined in a fixed order -> bit-reproducible.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part,
-                                                              int64_t nparts, int64_t stride,
-                                                              float* __restrict__ out, int n,
-                                                              int accumulate) {
-    __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < n) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int64_t p = grp;
-        for (; p + 12 < nparts; p += 16) {
-            s0 += part[p * stride + c];
-            s1 += part[(p + 4) * stride + c];
-            s2 += part[(p + 8) * stride + c];
-            s3 += part[(p + 12) * stride + c];
-        }
-        for (; p < nparts; p += 4) s0 += part[p * stride + c];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    sh[grp][lane] = s;
-    __syncthreads();
-    if (grp == 0 && c < n) {
-        float t = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
-        if (accumulate) t += out[c];
-        out[c] = t;
-    }
-}
-
-int launch_reduce_partials(const float* part, int64_t nparts, int64_t stride, float* out, int n,
-                           int accumulate, hipStream_t st) {
-    if (n <= 0) return MARL_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, part,
-                       nparts, stride, out, n, accumulate);
-    MARL_LAUNCH_CHECK();
-    return MARL_OK;
-}
-
 // stage 1 of a long partial reduction: parts [y * chunk, (y + 1) * chunk) -> row y * chunk, in
 // place (each block only touches its own 64 columns of its own chunk; fixed order).
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(float* __restrict__ part, int64_t nparts,
@@ -468,49 +428,6 @@ int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, floa
                        part, nparts, pstep, n, dgamma, dbeta, accumulate);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
-}
-
-// column sums (bias gradients): stage 1 -> scratch[blk][n], stage 2 -> out
-int colsum_blocks(int64_t rows) {
-    int64_t b = cdiv(rows, 256);
-    if (b > 2048) b = 2048;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld,
-                                                     int64_t rows, int n, int cw,
-                                                     int64_t rows_per_blk,
-                                                     float* __restrict__ scratch) {
-    __shared__ float sh[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rs = 64 / cw;  // row sub-lanes per wave
-    const int col = blockIdx.y * 64 + (lane % cw);
-    const int rsub = lane / cw;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
-    int64_t r1 = r0 + rows_per_blk;
-    if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    if (col < n)
-        for (int64_t r = r0 + wave * rs + rsub; r < r1; r += 4 * rs) s += x[r * ld + col];
-    for (int o = cw; o < 64; o <<= 1) s += __shfl_xor(s, o);
-    sh[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && rsub == 0 && col < n)
-        scratch[(size_t)blockIdx.x * n + col] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
-}
-
-int launch_colsum(const float* x, int ld, int64_t rows, int n, float* out, float* scratch,
-                  hipStream_t st) {
-    if (rows <= 0 || n <= 0) return MARL_OK;
-    const int nb = colsum_blocks(rows);
-    int cw = 1;
-    while (cw < n && cw < 64) cw <<= 1;
-    const int64_t rpb = cdiv(rows, nb);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb, (unsigned)cdiv(n, 64)), dim3(256), 0, st,
-                       x, ld, rows, n, cw, rpb, scratch);
-    MARL_LAUNCH_CHECK();
-    return launch_reduce_partials(scratch, nb, n, out, n, 0, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -1174,25 +1091,6 @@ int launch_rowdot(const float* a, int lda, const float* w, const float* b, float
                   int64_t rows, int n, hipStream_t st) {
     hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, a, lda, w, b,
                        out, rows, n);
-    MARL_LAUNCH_CHECK();
-    return MARL_OK;
-}
-
-__global__ void softmax_rows_kernel(const float* __restrict__ logits, int ld,
-                                    float* __restrict__ probs, int64_t rows, int n) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const float* l = logits + r * ld;
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) mx = fmaxf(mx, l[j]);
-    float den = 0.f;
-    for (int j = 0; j < n; ++j) den += expf(l[j] - mx);
-    for (int j = 0; j < n; ++j) probs[r * n + j] = expf(l[j] - mx) / den;
-}
-int launch_softmax_rows(const float* logits, int ld, float* probs, int64_t rows, int n,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv(rows, 128)), dim3(128), 0, st,
-                       logits, ld, probs, rows, n);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
