@@ -333,6 +333,9 @@ struct PanelBwdProb {
     int ldda;
     const float* da2;  // optional second addend of da [M, ldda2] (summed while staging)
     int ldda2;
+    // agg_na > 0: da is the gradient of the message MEAN; the mean over the other agents
+    // (self-adjoint, networks/message.py:5-17) is applied while staging (rows are a * agg_nb + b)
+    int agg_na, agg_nb;
     int m, nlayers;
     PanelBwdLayer layer[2];
     float* dx;  // out: d loss / d (input of the first layer) [M, lddx]

@@ -1089,10 +1089,11 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
             if (t > 0) {
                 float* dze2 = c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm;
                 float* dae1 = c.at(c.e.DAE1) + (size_t)(t - 1) * s_nm2;
-                MARL_TRY(launch_agg_msg(c.at(c.e.DMBAR), dze2, d.ld_nm, d.na, d.nb, d.n_m, st));
                 PanelBwdProb pe{};
-                pe.da = dze2;
+                pe.da = c.at(c.e.DMBAR);  // message mean applied while staging
                 pe.ldda = d.ld_nm;
+                pe.agg_na = d.na;
+                pe.agg_nb = d.nb;
                 pe.m = R;
                 pe.nlayers = 2;
                 pe.layer[0] = PanelBwdLayer{c.at(c.e.ZE2, t - 1), d.ld_nm, c.at(c.e.STE2, t - 1),

@@ -432,7 +432,33 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             const int lr = e / c4, k = (e % c4) * 4;
             const int r = m0 + lr;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < P.m && k < n4) {
+            if (r < P.m && k < n4 && P.agg_na > 1) {
+                const int na = P.agg_na, nb = P.agg_nb;
+                const float den = (float)(na - 1);
+                const float* base = P.da + (size_t)(r % nb) * P.ldda + k;
+                const size_t astr = (size_t)nb * P.ldda;
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int a0 = 0; a0 < na; a0 += 8) {  // 8 independent loads in flight
+                    float4 qv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a = a0 + u < na ? a0 + u : na - 1;
+                        qv[u] = *reinterpret_cast<const float4*>(base + (size_t)a * astr);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (a0 + u < na) {  // sequential over agents, as in the forward mean
+                            s.x += qv[u].x;
+                            s.y += qv[u].y;
+                            s.z += qv[u].z;
+                            s.w += qv[u].w;
+                        }
+                    }
+                }
+                const float4 me = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
+                v = make_float4((s.x - me.x) / den, (s.y - me.y) / den, (s.z - me.z) / den,
+                                (s.w - me.w) / den);
+            } else if (r < P.m && k < n4 && P.agg_na == 0) {
                 v = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
                 if (P.da2) {
                     const float4 w = *reinterpret_cast<const float4*>(P.da2 + (size_t)r * P.ldda2 + k);
