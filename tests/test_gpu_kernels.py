@@ -29,7 +29,8 @@ def _padded(t, ld):
 
 
 @pytest.mark.parametrize("m,n,k", [(96, 256, 160), (665, 92, 183), (37, 45, 24), (1, 4, 25),
-                                   (4096, 512, 368), (3000, 130, 7), (300, 2048, 624)])
+                                   (4096, 512, 368), (3000, 130, 7), (300, 2048, 624),
+                                   (32768 + 77, 368, 200)])  # last: many row blocks, ragged M and N
 @pytest.mark.parametrize("acc", [0, 1])
 def test_gemm_nt(device, m, n, k, acc):
     lib, check = _lib()
