@@ -193,7 +193,12 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
     MARL_TS();
 
     for (int l = 0; l < A.L; ++l) {
-        const CnnFwdLayer& Ly = A.layer[l];
+        // everything layer-specific is copied out of the (dynamically indexed) kernel-argument
+        // arrays ONCE per layer: a scalar load inside the tile loops costs an s_waitcnt lgkmcnt(0)
+        // that also drains the LDS queue
+        const CnnFwdLayer Ly = A.layer[l];
+        const FDiv fP = A.dP[l], fhout = A.dhout[l], fcin = A.dcin[l], fcpg = A.dcpg[l], fG = A.dG[l],
+                   fNT = A.dNT[l], fc4o = A.dc4o[l];
         const int P = Ly.P, cin = Ly.cin, cout = Ly.cout, K = Ly.K, ldk = Ly.ldk, hin = Ly.hin,
                   hout = Ly.hout;
         const int M = nrow * P, MT = (M + 15) >> 4, NT = (cout + 15) >> 4;
@@ -206,11 +211,11 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
         // ---- conv: Z[m][n] = sum_k im2col(in)[m][k] * W[n][k] + bias[n]; a 16x16 tile per turn
         const int steps = (K + 15) >> 4;
         for (int ti = wave; ti < MT * NT; ti += nwaves) {
-            const int mt = fdiv(ti, A.dNT[l]), nt = ti - mt * NT;
+            const int mt = fdiv(ti, fNT), nt = ti - mt * NT;
             const int m = mt * 16 + l16;
             const bool mv = m < M;
-            const int lr = fdiv(m, A.dP[l]), opos = m - lr * P;
-            const int oy = fdiv(opos, A.dhout[l]), ox = opos - oy * hout;
+            const int lr = fdiv(m, fP), opos = m - lr * P;
+            const int oy = fdiv(opos, fhout), ox = opos - oy * hout;
             const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
             const float* src = in + lr * in_per;
             const bool wcols = Ly.cols != nullptr && nt == 0;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
                         const int k = (st0 + i) * 16 + 4 * quad;
                         float4 a;
                         if (vec) {
-                            const int tap = fdiv(k, A.dcin[l]), ci = k - tap * cin;
+                            const int tap = fdiv(k, fcin), ci = k - tap * cin;
                             const int kh = tap / 3, kw = tap - 3 * kh;
                             const int iy = iy0 + kh, ix = ix0 + kw;
                             const bool ok = mv && k < K && (unsigned)iy < (unsigned)hin &&
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int kj = k + j;
-                                const int tap = fdiv(kj, A.dcin[l]), ci = kj - tap * cin;
+                                const int tap = fdiv(kj, fcin), ci = kj - tap * cin;
                                 const int kh = tap / 3, kw = tap - 3 * kh;
                                 const int iy = iy0 + kh, ix = ix0 + kw;
                                 const bool ok = mv && kj < K && (unsigned)iy < (unsigned)hin &&
@@ -284,19 +289,19 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
         MARL_TS();
         // ---- GroupNorm statistics (eps 1e-5, biased variance, two passes): wave per (patch,
         // group), four pairs walked together so their reduction chains overlap
-        const int G = Ly.G, cpg = (int)A.dcpg[l].d, cnt = P * cpg, npairs = nrow * G;
+        const int G = Ly.G, cpg = (int)fcpg.d, cnt = P * cpg, npairs = nrow * G;
         for (int pi0 = wave * 4; pi0 < npairs; pi0 += nwaves * 4) {
             const float* base[4];
             float sm[4], q[4], mean[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int pi = pi0 + u < npairs ? pi0 + u : npairs - 1;
-                const int lr = fdiv(pi, A.dG[l]), g = pi - lr * G;
+                const int lr = fdiv(pi, fG), g = pi - lr * G;
                 base[u] = Zb + lr * P * zs + g * cpg;
                 sm[u] = q[u] = 0.f;
             }
             for (int e = lane; e < cnt; e += 64) {
-                const int pos = fdiv(e, A.dcpg[l]);
+                const int pos = fdiv(e, fcpg);
                 const int off = pos * zs + (e - pos * cpg);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) sm[u] += base[u][off];
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) mean[u] = wave_sum(sm[u]) / (float)cnt;
             for (int e = lane; e < cnt; e += 64) {
-                const int pos = fdiv(e, A.dcpg[l]);
+                const int pos = fdiv(e, fcpg);
                 const int off = pos * zs + (e - pos * cpg);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -333,9 +338,9 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
             // ---- normalise + SiLU in place: the next layer's NHWC input
             const int c4 = cout >> 2;
             for (int idx = tid; idx < M * c4; idx += nthreads) {
-                const int m = fdiv(idx, A.dc4o[l]), c = (idx - m * c4) * 4;
-                const int lr = fdiv(m, A.dP[l]);
-                const int g = fdiv(c, A.dcpg[l]);
+                const int m = fdiv(idx, fc4o), c = (idx - m * c4) * 4;
+                const int lr = fdiv(m, fP);
+                const int g = fdiv(c, fcpg);
                 const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
                 float4* zp = reinterpret_cast<float4*>(Zb + m * zs + c);
                 const float4 z = *zp;
@@ -353,8 +358,8 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
             const int E = P * cout;
             for (int idx = tid; idx < nrow * E; idx += nthreads) {
                 const int lr = fdiv(idx, A.dE), e = idx - lr * E;
-                const int c = fdiv(e, A.dP[l]), pos = e - c * P;
-                const int g = fdiv(c, A.dcpg[l]);
+                const int c = fdiv(e, fP), pos = e - c * P;
+                const int g = fdiv(c, fcpg);
                 const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
                 const float zv = Zb[(lr * P + pos) * zs + c];
                 A.u[(row0 + lr) * (int64_t)A.ldu + e] = cnn_silu((zv - mean) * rstd * Ly.gamma[c] + Ly.beta[c]);
