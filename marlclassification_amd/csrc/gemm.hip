@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (batch.xcd_map) xcd_tile(batch.gx, batch.gy, batch.count, bx, by, bz);
-    const GemmProb& P = batch.p[bz];
+    // by value: the fields of a dynamically indexed kernel argument are otherwise re-loaded (scalar
+    // load + s_waitcnt lgkmcnt(0)) at every use, e.g. once per stored row in the epilogue
+    const GemmProb P = batch.p[bz];
     const int M = P.m;
     const int N = P.n;  // LSTM: number of hidden units (B has 4*N rows)
     const int n0 = by * (LSTM ? 32 : BN);

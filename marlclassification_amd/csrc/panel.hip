@@ -215,7 +215,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
     lds_barrier();
 
     for (int l = 0; l < P.nlayers; ++l) {
-        const PanelLayer& Lr = P.layer[l];
+        const PanelLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
         const float* lbias = prm + (l == 0 ? 0 : 3 * P.layer[0].n);
         const float* lgamma = lbias + Lr.n;
         const float* lbeta = lgamma + Lr.n;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
 
     int prm_off = 0;
     for (int l = 0; l < P.nlayers; ++l) {
-        const PanelBwdLayer& Lr = P.layer[l];
+        const PanelBwdLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
         const int n = Lr.n, ds = panel_stride(n), n16 = (n + 15) & ~15;
         const float* lgamma = prm + prm_off;
         const float* lbeta = lgamma + n;
