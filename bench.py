@@ -68,26 +68,33 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
     y = th.randint(0, C3["nb_class"], (nb,), generator=th.Generator().manual_seed(1))
     m = {k: th.zeros_like(v) for k, v in params.items()}
     v = {k: th.zeros_like(x) for k, x in params.items()}
-    times = []
-    t_start = time.perf_counter()
-    it = 0
-    while True:
-        inp = mo.draw_episode_inputs(cfg, NA, nb, NS, IMG[1:], 42 + it)
-        t0 = time.perf_counter()
-        _, _, grads = mo.train_iteration(params, cfg, img, y, inp, NS, GAMMA, faithful_crop=True)
-        mo.adam_step(params, grads, m, v, it + 1, LR)
-        times.append(time.perf_counter() - t0)
-        it += 1
-        if it >= 2 and time.perf_counter() - t_start > budget_s or it >= 6:
-            break
-    best = sum(times[1:]) / len(times[1:]) if len(times) > 1 else times[0]
+
+    def run(faithful: bool, budget: float, max_it: int) -> tuple:
+        times = []
+        t_start = time.perf_counter()
+        it = 0
+        while True:
+            inp = mo.draw_episode_inputs(cfg, NA, nb, NS, IMG[1:], 42 + it)
+            t0 = time.perf_counter()
+            _, _, grads = mo.train_iteration(params, cfg, img, y, inp, NS, GAMMA, faithful_crop=faithful)
+            mo.adam_step(params, grads, m, v, it + 1, LR)
+            times.append(time.perf_counter() - t0)
+            it += 1
+            if it >= 2 and time.perf_counter() - t_start > budget or it >= max_it:
+                break
+        return (sum(times[1:]) / len(times[1:]) if len(times) > 1 else times[0]), len(times)
+
+    best, n_it = run(True, budget_s, 6)
+    best_gather, _ = run(False, 8.0, 4)  # same path with an O(f^2) index-gather crop
     return {
         "value": nb * NA * NS / best,
+        "value_gather_crop": nb * NA * NS / best_gather,
         "unit": "agent-env-steps/s",
         "cores": th.get_num_threads(),
         "kind": "port",
-        "sample": f"{len(times)} full train iterations (1st discarded) of the same config at "
-                  f"batch {nb}, reference-faithful mask+masked_select crop, torch-CPU fp32",
+        "sample": f"{n_it} full train iterations (1st discarded) of the same config at batch {nb}, "
+                  "reference-faithful mask+masked_select crop, torch-CPU fp32; value_gather_crop = "
+                  "the same with an O(f^2) index-gather crop",
     }
 
 
