@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MARL_ABI_VERSION 1
+#define MARL_ABI_VERSION 2
 
 #define MARL_OK 0
 #define MARL_EINVAL (-1)   /* bad configuration / null pointer          */
@@ -131,10 +131,13 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
 /* loss.backward() through the episode (training/trainer.py:115): given dL/d(step_preds)
  * [Ns,R,nC], dL/d(step_logp) [Ns,R], dL/d(step_values) [Ns,R] (any may be NULL = zero),
  * writes dL/d(param) for every parameter into grads_host[i] (tight reference shapes,
- * overwritten, not accumulated). */
+ * overwritten, not accumulated).  `img` is the image batch of the matching
+ * marl_episode_forward(train = 1) call: the first convolution's weight gradient re-gathers
+ * the patches at the saved positions instead of keeping im2col rows in episode_ws (autograd
+ * would keep the observation tensors alive the same way). */
 int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
-                          const float* g_preds, const float* g_logp, const float* g_values,
-                          float* const* grads_host, void* stream);
+                          const void* img, const float* g_preds, const float* g_logp,
+                          const float* g_values, float* const* grads_host, void* stream);
 
 /* Loss of Trainer.train_epoch (training/trainer.py:76-111; training/functions.py:7-55)
  * and its gradient w.r.t. the episode outputs in one pass.

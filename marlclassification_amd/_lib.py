@@ -13,7 +13,7 @@ from typing import Optional
 
 MARL_MAX_CNN_LAYERS = 5
 MARL_MAX_ACTIONS = 16
-MARL_ABI_VERSION = 1
+MARL_ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmarl_hip.so")
@@ -85,7 +85,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_patch_gather.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.marl_transition.argtypes = [_vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _vp]
     lib.marl_episode_forward.argtypes = [_cfgp, _vp, _vp] + [_vp] * 13 + [_i, _vp]
-    lib.marl_episode_backward.argtypes = [_cfgp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]
+    lib.marl_episode_backward.argtypes = [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]
     lib.marl_a2c_loss_fwd_bwd.argtypes = (
         [_cfgp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
     )

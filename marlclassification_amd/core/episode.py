@@ -38,6 +38,7 @@ class _EpisodeFunction(th.autograd.Function):
         out = eng.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0, draws.cc0,
                                   draws.noise, None, True)
         ctx.eng = eng
+        ctx.generation = eng.fwd_generation  # the workspace holds THIS episode until the next one
         ctx.names = names
         ctx.shapes = [p.shape for p in params]
         ctx.mark_non_differentiable(out.step_pos, out.step_actions)
@@ -47,7 +48,7 @@ class _EpisodeFunction(th.autograd.Function):
     def backward(ctx, g_preds, g_logp, g_values, _g_pos, _g_act):
         eng: HipEngine = ctx.eng
         grads = {k: th.empty(s, device=eng.device) for k, s in zip(ctx.names, ctx.shapes)}
-        eng.episode_backward(g_preds, g_logp, g_values, grads)
+        eng.episode_backward(g_preds, g_logp, g_values, grads, generation=ctx.generation)
         return (None, None, None, None) + tuple(grads[k] for k in ctx.names)
 
 

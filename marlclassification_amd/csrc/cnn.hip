@@ -850,6 +850,409 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
     return MARL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Convolution weight gradient from the activations (backward of networks/vision.py:33-35,
+// training/trainer.py:115).  PERSISTENT workgroups (a few per CU) walk chunks of `rb` patches:
+//   dZ_l chunk -> LDS; the layer's input -> LDS with a zero border (raw image patch gathered at
+//   the saved positions for the first layer, SiLU(GroupNorm(Z_{l-1})) recomputed from the saved
+//   pre-norm output otherwise); then dW[co][k] += sum_m dZ[m][co] * im2col(in)[m][k] on 16x16x4
+//   f32 MFMA tiles whose B fragments are gathered straight from the LDS image (implicit im2col,
+//   the zero border makes every tap address valid).  The accumulators live in registers across
+//   ALL chunks; every workgroup writes one partial slab at the end and a fixed-order reduction
+//   sums the slabs (bit-reproducible, no float atomics).  The next chunk's global loads are
+//   issued before the current chunk's matrix phase (register prefetch).
+// Wave roles: (cout-tile group, k-tile group, row-step phase); waves that share tiles but walk
+// different row steps are summed through LDS once at the end.
+// ---------------------------------------------------------------------------
+constexpr int kWgPD = 4;   // prefetched float4 of dZ per thread
+constexpr int kWgPZ = 4;   // prefetched float4 of Z_{l-1} per thread
+constexpr int kWgPR = 14;  // prefetched raw pixels per thread (first layer)
+
+template <int NCT, int NKT, bool FIRST>
+__global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* In = lds;                                       // [rb][hp][hp][cs]
+    float* Dz = lds + A.off_dz;                            // [Mpad][zs]
+    int* tab = reinterpret_cast<int*>(lds + A.off_tab);    // [Mpad] float offset of row m's window
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, l16 = lane & 15;
+    const int cin = A.cin, cout = A.cout, P = A.P, K = A.K, hp = A.hp, cs = A.cs, zs = A.zs;
+    const int rb = A.rb, in_per = A.in_per;
+    const int Mfull = rb * P, Mpad = (Mfull + 3) & ~3;
+    const int ms = A.ms;
+    const int ms_id = wave % ms, tg = wave / ms;
+    const int ktg = tg % A.tgk, ctg = tg / A.tgk;
+    const int kt0 = blockIdx.y * A.nkt_slab + ktg * NKT;
+    const int kt_end = min((int)(blockIdx.y + 1) * A.nkt_slab, A.nkt);
+    const int ct0 = ctg * NCT;
+
+    // per-lane constants: where inside a row's 3x3 window column kcol = kt * 16 + l16 lives
+    int toff[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+        int kc = (kt0 + j) * 16 + l16;
+        kc = kc < K ? kc : K - 1;
+        const int tap = fdiv(kc, A.dcin), ci = kc - tap * cin;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        toff[j] = (kh * hp + kw) * cs + ci;
+    }
+    int aoff[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) {
+        const int ct = ct0 + i < A.nct ? ct0 + i : A.nct - 1;
+        aoff[i] = ct * 16 + l16;
+    }
+    cf32x4 acc[NCT][NKT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) acc[i][j] = cf32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- one-time LDS set-up: zeros (borders, padding rows), row table
+    for (int i = tid; i < A.lds_floats; i += 512) lds[i] = 0.f;
+    __syncthreads();
+    for (int m = tid; m < Mpad; m += 512) {
+        const int mm = m < Mfull ? m : 0;
+        const int lr = fdiv(mm, A.dP), opos = mm - lr * P;
+        const int oy = fdiv(opos, A.dhout), ox = opos - oy * A.hout;
+        tab[m] = lr * in_per + (2 * oy * hp + 2 * ox) * cs;
+    }
+
+    // ---- staging roles (fixed per thread: 512 is a multiple of cout / 4 and of cin / 4)
+    const int c4o = cout >> 2, c4i = cin >> 2;
+    const int dz_c = (tid % c4o) * 4, dz_m0 = tid / c4o, dz_mstep = 512 / c4o;
+    const int zi_c = FIRST ? 0 : (tid % c4i) * 4, zi_p0 = FIRST ? 0 : tid / c4i,
+              zi_pstep = FIRST ? 1 : 512 / c4i;
+    float4 gm4 = make_float4(0.f, 0.f, 0.f, 0.f), bt4 = gm4;
+    int zi_g = 0;
+    if (!FIRST) {
+        gm4 = *reinterpret_cast<const float4*>(A.gamma + zi_c);
+        bt4 = *reinterpret_cast<const float4*>(A.beta + zi_c);
+        zi_g = zi_c / (cin / A.G);
+    }
+    const int Pin = A.hin * A.hin;
+    const int ff = A.hin * A.hin, pe = cin * ff;   // first layer: hin = f
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 pd[kWgPD], pz[kWgPZ];
+    float2 ps[kWgPZ];
+    float pr[kWgPR];
+    const float* imgf = static_cast<const float*>(A.img);
+    const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+
+    auto prefetch = [&](int chunk) {
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+        const int M = nrow * P;
+        const float* dsrc = A.dz + row0 * P * (int64_t)cout + dz_c;
+#pragma unroll
+        for (int i = 0; i < kWgPD; ++i) {
+            const int m = dz_m0 + i * dz_mstep;
+            pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) pd[i] = *reinterpret_cast<const float4*>(dsrc + (int64_t)m * cout);
+        }
+        if (FIRST) {
+#pragma unroll
+            for (int i = 0; i < kWgPR; ++i) {
+                const int idx = tid + i * 512;
+                pr[i] = 0.f;
+                if (idx < nrow * pe) {
+                    const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
+                    const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
+                    const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
+                    const int64_t r = row0 + lr;
+                    const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
+                    const int64_t off = (((r % A.nb) * A.c_img + ci) * (int64_t)A.H + (p0 + iy)) * A.W + (p1 + ix);
+                    pr[i] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
+                }
+            }
+        } else {
+            const float* zsrc = A.zin + row0 * Pin * (int64_t)cin + zi_c;
+#pragma unroll
+            for (int i = 0; i < kWgPZ; ++i) {
+                const int pl = zi_p0 + i * zi_pstep;  // patch-major input position
+                pz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                ps[i] = make_float2(0.f, 0.f);
+                if (pl < nrow * Pin) {
+                    pz[i] = *reinterpret_cast<const float4*>(zsrc + (int64_t)pl * cin);
+                    const int lr = fdiv(pl, A.dPin);
+                    ps[i] = *reinterpret_cast<const float2*>(A.gst + ((row0 + lr) * A.G + zi_g) * 2);
+                }
+            }
+        }
+    };
+    auto stage = [&](int chunk) {
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+#pragma unroll
+        for (int i = 0; i < kWgPD; ++i) {
+            const int m = dz_m0 + i * dz_mstep;
+            if (m < Mpad) {  // rows past this chunk's M hold zeros (they multiply stale inputs)
+                *reinterpret_cast<float4*>(Dz + m * zs + dz_c) = pd[i];
+                bsum.x += pd[i].x;
+                bsum.y += pd[i].y;
+                bsum.z += pd[i].z;
+                bsum.w += pd[i].w;
+            }
+        }
+        if (FIRST) {
+#pragma unroll
+            for (int i = 0; i < kWgPR; ++i) {
+                const int idx = tid + i * 512;
+                if (idx < nrow * pe) {
+                    const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
+                    const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
+                    const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
+                    In[lr * in_per + ((iy + 1) * hp + ix + 1) * cs + ci] = pr[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kWgPZ; ++i) {
+                const int pl = zi_p0 + i * zi_pstep;
+                if (pl < nrow * Pin) {
+                    const int lr = fdiv(pl, A.dPin), ipos = pl - lr * Pin;
+                    const int iy = fdiv(ipos, A.dhin), ix = ipos - iy * A.hin;
+                    const float mean = ps[i].x, rstd = ps[i].y;
+                    float4 v;
+                    v.x = cnn_silu((pz[i].x - mean) * rstd * gm4.x + bt4.x);
+                    v.y = cnn_silu((pz[i].y - mean) * rstd * gm4.y + bt4.y);
+                    v.z = cnn_silu((pz[i].z - mean) * rstd * gm4.z + bt4.z);
+                    v.w = cnn_silu((pz[i].w - mean) * rstd * gm4.w + bt4.w);
+                    *reinterpret_cast<float4*>(In + lr * in_per + ((iy + 1) * hp + ix + 1) * cs + zi_c) = v;
+                }
+            }
+        }
+    };
+
+    int chunk = blockIdx.x;
+    if (chunk < A.nchunks) prefetch(chunk);
+    for (; chunk < A.nchunks; chunk += gridDim.x) {
+        __syncthreads();  // every wave is done with the previous chunk's LDS image
+        stage(chunk);
+        __syncthreads();
+        if (chunk + (int)gridDim.x < A.nchunks) prefetch(chunk + gridDim.x);
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+        const int msteps = (nrow * P + 3) >> 2;
+        for (int s = ms_id; s < msteps; s += ms) {
+            const int m = s * 4 + quad;
+            const int rbase = tab[m];
+            float a[NCT], b[NKT];
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) a[i] = Dz[m * zs + aoff[i]];
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) b[j] = In[rbase + toff[j]];
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int i = 0; i < NCT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- waves that shared tiles (different row-step phases) are summed through LDS in a fixed
+    // order, then the workgroup's partial slab goes to global
+    __syncthreads();
+    float* red = lds;  // [8 waves][NCT * NKT][64 lanes][4]
+    if (ms > 1) {
+#pragma unroll
+        for (int i = 0; i < NCT; ++i)
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+                *reinterpret_cast<cf32x4*>(red + ((wave * (NCT * NKT) + i * NKT + j) * 64 + lane) * 4) = acc[i][j];
+        __syncthreads();
+    }
+    if (ms_id == 0) {
+        float* pw = A.part_w + (size_t)blockIdx.x * cout * K;  // grid.y slabs are disjoint in k
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            if (ct0 + i >= A.nct) continue;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                const int kt = kt0 + j;
+                if (kt >= kt_end) continue;
+                cf32x4 v = acc[i][j];
+                for (int q = 1; q < ms; ++q) {
+                    const cf32x4 u = *reinterpret_cast<const cf32x4*>(
+                        red + (((wave + q) * (NCT * NKT) + i * NKT + j) * 64 + lane) * 4);
+                    v += u;
+                }
+                const int kcol = kt * 16 + l16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (ct0 + i) * 16 + 4 * quad + r;
+                    if (co < cout && kcol < K) pw[(size_t)co * K + kcol] = v[r];
+                }
+            }
+        }
+    }
+    // bias gradient: column sums of dZ, taken from the staged values (threads with equal
+    // tid % (cout / 4) staged the same four channels)
+    if (A.part_b && blockIdx.y == 0) {
+        __syncthreads();
+        float4* sh4 = reinterpret_cast<float4*>(lds);
+        sh4[tid] = bsum;
+        __syncthreads();
+        if (tid < c4o) {
+            float4 t = sh4[tid];
+            for (int q = 1; q < dz_mstep; ++q) {
+                const float4 u = sh4[q * c4o + tid];
+                t.x += u.x;
+                t.y += u.y;
+                t.z += u.z;
+                t.w += u.w;
+            }
+            *reinterpret_cast<float4*>(A.part_b + (size_t)blockIdx.x * cout + tid * 4) = t;
+        }
+    }
+}
+
+// picks the wave roles and the chunk size; returns the dynamic LDS floats (0 = unsupported)
+static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
+    if ((a.cout & 3) || 512 % (a.cout / 4) != 0 || a.cout > 2048) return 0;
+    if (!a.first && ((a.cin & 3) || 512 % (a.cin / 4) != 0 || a.cin % a.G != 0 || ((a.cin / a.G) & 3)))
+        return 0;
+    if (a.hin > 200 || a.rows <= 0) return 0;
+    a.nct = (a.cout + 15) / 16;
+    a.nkt = (a.K + 15) / 16;
+    // tile slabs over grid.y when one workgroup (8 waves x <= 18 tile slots) cannot hold them all
+    const int max_tiles = 8 * 18;
+    a.slabs = (int)cdiv((int64_t)a.nct * a.nkt, max_tiles);
+    a.nkt_slab = (int)cdiv(a.nkt, a.slabs);
+    a.slabs = (int)cdiv(a.nkt, a.nkt_slab);
+    // wave roles: best slot utilisation, then the fewest row-step phases
+    static const int kShapes[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 5}, {1, 9}, {2, 5}, {2, 9}};
+    double best = -1.0;
+    int bct = 0, bkt = 0, btgc = 0, btgk = 0, bms = 0;
+    for (const auto& s : kShapes) {
+        if (a.first && (s[0] != 1 || s[1] > 3)) continue;  // instantiated shapes
+        for (int tgc = 1; tgc <= 8; tgc *= 2)
+            for (int tgk = 1; tgc * tgk <= 8; tgk *= 2) {
+                const int ms = 8 / (tgc * tgk);
+                if (tgc * s[0] < a.nct || tgk * s[1] < a.nkt_slab) continue;
+                const double util = (double)a.nct * a.nkt_slab * ms / (8.0 * s[0] * s[1]);
+                const double score = util - 1e-3 * ms - 1e-4 * s[0] * s[1];
+                if (score > best) {
+                    best = score;
+                    bct = s[0];
+                    bkt = s[1];
+                    btgc = tgc;
+                    btgk = tgk;
+                    bms = ms;
+                }
+            }
+    }
+    if (best < 0) return 0;
+    a.tgc = btgc;
+    a.tgk = btgk;
+    a.ms = bms;
+    a.sct = bct;
+    a.skt = bkt;
+    a.hp = a.hin + 2;
+    a.cs = (a.cin & 3) ? a.cin : a.cin + 8;
+    a.zs = ((a.cout + 15) / 32) * 32 + 16;
+    a.in_per = a.hp * a.hp * a.cs;
+    a.dP = make_fdiv(a.P);
+    a.dhout = make_fdiv(a.hout);
+    a.dPin = make_fdiv(a.hin * a.hin);
+    a.dhin = make_fdiv(a.hin);
+    a.dcin = make_fdiv(a.cin);
+    a.dc4o = make_fdiv(a.cout / 4);
+    a.dc4i = make_fdiv(a.cin >= 4 ? a.cin / 4 : 1);
+    a.dpe = make_fdiv(a.cin * a.hin * a.hin);
+    a.dff = make_fdiv(a.hin * a.hin);
+    a.df = make_fdiv(a.hin);
+    static int lds_cap_kb = 0, rb_cap = 0;
+    if (!lds_cap_kb) {
+        const char* e = getenv("MARL_WGRAD_LDS_KB");
+        lds_cap_kb = e ? atoi(e) : 76;
+        const char* r = getenv("MARL_WGRAD_RB");
+        rb_cap = r ? atoi(r) : 16;
+        if (rb_cap < 1) rb_cap = 1;
+    }
+    const size_t red = a.ms > 1 ? (size_t)8 * bct * bkt * 256 : 0;
+    for (int rb = rb_cap; rb >= 1; --rb) {
+        const int M = rb * a.P, Mpad = (M + 3) & ~3;
+        if ((int64_t)M * a.cout > (int64_t)kWgPD * 512 * 4) continue;
+        if (a.first ? (int64_t)rb * a.cin * a.hin * a.hin > (int64_t)kWgPR * 512
+                    : (int64_t)rb * a.hin * a.hin * a.cin > (int64_t)kWgPZ * 512 * 4)
+            continue;
+        size_t off = ((size_t)rb * a.in_per + 3) & ~(size_t)3;
+        const size_t off_dz = off;
+        off += (size_t)Mpad * a.zs;
+        const size_t off_tab = off;
+        off += Mpad;
+        size_t tot = off > red ? off : red;
+        if (tot < 2048) tot = 2048;  // bias reduction scratch
+        if (tot * sizeof(float) > (size_t)lds_cap_kb * 1024 && rb > 1) continue;
+        if (tot * sizeof(float) > 150 * 1024) return 0;
+        a.rb = rb;
+        a.off_dz = (int)off_dz;
+        a.off_tab = (int)off_tab;
+        a.lds_floats = (int)tot;
+        a.nchunks = (int)cdiv(a.rows, rb);
+        static int wg_per_cu = 0;
+        if (!wg_per_cu) {
+            const char* e = getenv("MARL_WGRAD_WGS");
+            wg_per_cu = e ? atoi(e) : 2;
+            if (wg_per_cu < 1) wg_per_cu = 1;
+        }
+        int blocks = 256 * wg_per_cu / a.slabs;
+        if (blocks < 64) blocks = 64;
+        a.blocks = a.nchunks < blocks ? a.nchunks : blocks;
+        return tot;
+    }
+    return 0;
+}
+
+int cnn_wgrad_supported(const CnnWgradArgs& a0) {
+    if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
+    if (getenv("MARL_CNN_WGRAD") && getenv("MARL_CNN_WGRAD")[0] == '0') return 0;
+    CnnWgradArgs a = a0;
+    return cnn_wgrad_plan(a) > 0;
+}
+
+int cnn_wgrad_blocks(const CnnWgradArgs& a0) {
+    CnnWgradArgs a = a0;
+    return cnn_wgrad_plan(a) > 0 ? a.blocks : 0;
+}
+
+template <int NCT, int NKT, bool FIRST>
+static int wgrad_launch(const CnnWgradArgs& a, size_t lds, hipStream_t st) {
+    auto kern = cnn_wgrad_kernel<NCT, NKT, FIRST>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;  // per process; one process drives one GPU (see marl_hip.h)
+        if (!raised) {
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.blocks, (unsigned)a.slabs), dim3(512), lds, st, a);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+int launch_cnn_wgrad(CnnWgradArgs& a, hipStream_t st) {
+    const size_t fl = cnn_wgrad_plan(a);
+    if (!fl) {
+        set_error("conv weight gradient: shape outside the fused kernel's range");
+        return MARL_ELIMIT;
+    }
+    const size_t lds = fl * sizeof(float);
+    const int sct = a.sct, skt = a.skt;
+#define MARL_WG(CT, KT)                                                        \
+    if (sct == CT && skt == KT)                                                \
+        return a.first ? wgrad_launch<1, (KT <= 3 ? KT : 1), true>(a, lds, st) \
+                       : wgrad_launch<CT, KT, false>(a, lds, st);
+    MARL_WG(1, 1) MARL_WG(1, 2) MARL_WG(1, 3) MARL_WG(1, 5) MARL_WG(1, 9) MARL_WG(2, 5) MARL_WG(2, 9)
+#undef MARL_WG
+    set_error("conv weight gradient: no kernel for tile shape %d x %d", sct, skt);
+    return MARL_ELIMIT;
+}
+
 // Environment.observe(): obs[r, c, y, x] = img[b, c, p0 + y, p1 + x]
 __global__ void patch_gather_kernel(const float* __restrict__ img, const int64_t* __restrict__ pos,
                                     float* __restrict__ obs, int64_t rows, int nb, int c, int H,

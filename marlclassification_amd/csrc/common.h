@@ -438,6 +438,41 @@ int cnn_dgrad_supported(const CnnDgradArgs& a);
 int cnn_dgrad_blocks(const CnnDgradArgs& a);
 int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// Convolution weight gradient straight from the activations (cnn.hip): for every patch,
+//   dW_l[co][tap * cin + ci] += sum over output positions of dZ_l[pos][co] * A_{l-1}[in(pos, tap)][ci]
+// with A_{l-1} = SiLU(GroupNorm(Z_{l-1})) recomputed from the saved pre-norm output (or the raw
+// image patch for the first layer) - the im2col rows never exist in HBM.
+// ---------------------------------------------------------------------------
+struct CnnWgradArgs {
+    const float* dz;      // [rows * P][cout]   gradient of this layer's conv output
+    const void* img;      // first layer: image batch [nb][c_img][H][W] float or uint8
+    const int32_t* pos;   // first layer: [rows][2] patch positions (row r reads image r % nb)
+    const float* zin;     // deeper layers: [rows * hin * hin][cin] pre-norm output of the layer below
+    const float* gst;     // deeper layers: [rows][G][2] mean / rstd of the layer below
+    const float *gamma, *beta;  // affine of the layer below
+    float* part_w;        // [blocks][cout * K] per-workgroup partial sums (k = tap * cin + ci)
+    float* part_b;        // [blocks][cout]     per-workgroup partial bias gradient
+    int64_t rows;
+    int first, img_u8, nb, c_img, H, W;
+    int cin, cout, hin, hout, P, G, K;
+    // filled by the launcher
+    int rb, nchunks, blocks;      // patches per chunk, chunks, persistent workgroups (grid.x)
+    int hp, cs, zs, in_per;       // padded input side / channel stride / dZ row stride / floats per patch
+    int off_dz, off_tab, lds_floats;
+    int nct, nkt, nkt_slab, slabs;  // 16-wide tiles of cout / K, k tiles per grid.y slab
+    int tgc, tgk, ms;             // wave roles: cout-tile groups x k-tile groups x row-step interleave
+    int sct, skt;                 // accumulator tiles per wave (template shape of the launch)
+    FDiv dP, dhout, dPin, dhin, dcin, dc4o, dc4i, dpe, dff, df;
+};
+int cnn_wgrad_supported(const CnnWgradArgs& a);
+int cnn_wgrad_blocks(const CnnWgradArgs& a);   // partial slabs the launch writes
+int launch_cnn_wgrad(CnnWgradArgs& a, hipStream_t st);
+// out[i * ldc + j] = sum over z < splits (fixed order) of part[z * stride + i * nj + j];
+// bias (nullable): same over bpart[z * ni + i]
+int launch_slab_reduce(const float* part, int64_t stride, int splits, float* c, int ldc, int ni,
+                       int nj, const float* bpart, float* bias, hipStream_t st);
+
 int launch_gather_im2col(const void* img, int img_u8, const int32_t* pos, float* cols, int ldk,
                          int na, int nb, int c_img, int cin, int H, int W, int f, hipStream_t st);
 // same but from pre-gathered patches obs [R, c_img, f, f] (standalone step API)

@@ -245,7 +245,56 @@ struct ELayout {
     size_t PART, TNS, LOSS;
     size_t part_floats, tns_bytes, loss_floats;
     size_t total;
+    // which fused CNN kernels cover this shape (decides what is kept for backward)
+    bool fused_fwd;                          // one launch for the whole extractor
+    bool wgrad_ok[MARL_MAX_CNN_LAYERS];      // weight gradient from the activations (no im2col rows)
+    bool dgrad_ok[MARL_MAX_CNN_LAYERS];      // fused transposed conv + GroupNorm backward (l >= 1)
 };
+
+static CnnFwdArgs cnn_fwd_shape(const Dims& d) {
+    CnnFwdArgs a{};
+    a.rows = d.R;
+    a.nb = d.nb;
+    a.c_img = d.c_img;
+    a.H = d.H;
+    a.W = d.W;
+    a.f = d.f;
+    a.L = d.L;
+    for (int l = 0; l < d.L; ++l)
+        a.layer[l] = CnnFwdLayer{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 d.ch[l], d.ch[l + 1], d.grp[l], d.hw[l], d.hw[l + 1], d.P[l], d.K[l],
+                                 d.ldk[l]};
+    return a;
+}
+static CnnWgradArgs cnn_wgrad_shape(const Dims& d, int l) {
+    CnnWgradArgs g{};
+    g.rows = d.NR;
+    g.first = l == 0;
+    g.nb = d.nb;
+    g.c_img = d.c_img;
+    g.H = d.H;
+    g.W = d.W;
+    g.cin = d.ch[l];
+    g.cout = d.ch[l + 1];
+    g.hin = d.hw[l];
+    g.hout = d.hw[l + 1];
+    g.P = d.P[l];
+    g.G = l > 0 ? d.grp[l - 1] : 1;
+    g.K = d.K[l];
+    return g;
+}
+static CnnDgradArgs cnn_dgrad_shape(const Dims& d, int l) {
+    CnnDgradArgs g{};
+    g.rows = d.NR;
+    g.cin = d.ch[l];
+    g.cout = d.ch[l + 1];
+    g.hin = d.hw[l];
+    g.hout = d.hw[l + 1];
+    g.P = d.P[l];
+    g.Pin = d.P[l - 1];
+    g.G = d.grp[l - 1];
+    return g;
+}
 
 static void make_elayout(const Dims& d, int train, ELayout& e) {
     Bump b;
@@ -264,11 +313,26 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         s.off = b.take(n * steps);
         s.stride = train ? n : 0;
     };
+    auto once = [&](SBuf& s, size_t n) {  // one slice shared by every step (forward scratch)
+        s.off = b.take(n);
+        s.stride = 0;
+    };
+    e.fused_fwd = cnn_fwd_supported(cnn_fwd_shape(d)) != 0;
+    for (int l = 0; l < MARL_MAX_CNN_LAYERS; ++l) e.wgrad_ok[l] = e.dgrad_ok[l] = false;
     for (int l = 0; l < d.L; ++l) {
-        per(e.COLS[l], R * d.P[l] * d.ldk[l]);
+        e.wgrad_ok[l] = cnn_wgrad_supported(cnn_wgrad_shape(d, l)) != 0;
+        if (l > 0) e.dgrad_ok[l] = cnn_dgrad_supported(cnn_dgrad_shape(d, l)) != 0;
+    }
+    for (int l = 0; l < d.L; ++l) {
+        // im2col rows: kept for every step only when the weight gradient needs them (shapes the
+        // activation-based kernel does not cover); one scratch slice for the unfused forward
+        if (train && !e.wgrad_ok[l])
+            per(e.COLS[l], R * d.P[l] * d.ldk[l]);
+        else if (!e.fused_fwd)
+            once(e.COLS[l], R * d.P[l] * d.ldk[l]);
         per(e.Z[l], R * d.P[l] * d.ch[l + 1]);
         per(e.GST[l], R * d.grp[l] * 2);
-        if (l + 1 < d.L) per(e.A[l], R * d.P[l] * d.ch[l + 1]);
+        if (l + 1 < d.L && !e.fused_fwd) once(e.A[l], R * d.P[l] * d.ch[l + 1]);
     }
     per(e.U, R * d.ld_nin);
     per(e.MBAR, R * d.ld_nm);
@@ -327,8 +391,9 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         }
         for (int l = 0; l < d.L; ++l) {
             e.DZ[l] = b.take(NR * d.P[l] * d.ch[l + 1]);
-            e.DCOLS[l] = l > 0 ? b.take(NR * d.P[l] * d.ldk[l]) : 0;
-            e.DA[l] = (l + 1 < d.L) ? b.take(NR * d.P[l] * d.ch[l + 1]) : 0;
+            // only the unfused layer backward materialises dCOLS_l and dA_{l-1}
+            e.DCOLS[l] = (l > 0 && !e.dgrad_ok[l]) ? b.take(NR * d.P[l] * d.ldk[l]) : 0;
+            e.DA[l] = (l + 1 < d.L && !e.dgrad_ok[l + 1]) ? b.take(NR * d.P[l] * d.ch[l + 1]) : 0;
         }
         // scratch sizes: maxima over every use
         size_t part = 0, tns = 0;
@@ -348,18 +413,8 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_part(ln_bwd_blocks(r, d.n_mo), d.n_mo);
         upd_part(ln_bwd_blocks(r, d.n_m), d.n_m);
         for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr, d.ch[l + 1]), d.ch[l + 1]);
-        for (int l = 1; l < d.L; ++l) {  // fused layer backward: one partial row per workgroup
-            CnnDgradArgs g{};
-            g.rows = nr;
-            g.cin = d.ch[l];
-            g.cout = d.ch[l + 1];
-            g.hin = d.hw[l];
-            g.hout = d.hw[l + 1];
-            g.P = d.P[l];
-            g.Pin = d.P[l - 1];
-            g.G = d.grp[l - 1];
-            if (cnn_dgrad_supported(g)) upd_part(cnn_dgrad_blocks(g), d.ch[l]);
-        }
+        for (int l = 1; l < d.L; ++l)  // fused layer backward: one partial row per workgroup
+            if (e.dgrad_ok[l]) upd_part(cnn_dgrad_blocks(cnn_dgrad_shape(d, l)), d.ch[l]);
         upd_tn(d.nC, d.nlb, nr);
         upd_tn(d.nlb, d.n_b, nr);
         upd_tn(1, d.nla, nr);
@@ -374,7 +429,15 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_tn(4 * d.n_a, d.nin, nr);
         upd_tn(4 * d.n_a, d.n_a, nr);
         upd_tn(d.n_d, 2, nr);
-        for (int l = 0; l < d.L; ++l) upd_tn(d.ch[l + 1], d.K[l], nr * d.P[l]);
+        for (int l = 0; l < d.L; ++l) {
+            if (e.wgrad_ok[l]) {  // per-workgroup partial slabs of the activation-based kernel
+                const size_t v = (size_t)cnn_wgrad_blocks(cnn_wgrad_shape(d, l)) *
+                                 ((size_t)d.ch[l + 1] * d.K[l] + d.ch[l + 1]) * sizeof(float);
+                tns = v > tns ? v : tns;
+            } else {
+                upd_tn(d.ch[l + 1], d.K[l], nr * d.P[l]);
+            }
+        }
         e.part_floats = part;
         e.tns_bytes = tns;
         e.PART = b.take(part);
@@ -492,14 +555,14 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
         a.L = d.L;
         for (int l = 0; l < d.L; ++l)
             a.layer[l] = CnnFwdLayer{c.wp(4 * l), c.wp(4 * l + 1), c.wp(4 * l + 2), c.wp(4 * l + 3),
-                                     keep ? c.at(c.e.COLS[l], t) : nullptr,
+                                     keep && !c.e.wgrad_ok[l] ? c.at(c.e.COLS[l], t) : nullptr,
                                      keep ? c.at(c.e.Z[l], t) : nullptr,
                                      keep ? c.at(c.e.GST[l], t) : nullptr,
                                      d.ch[l], d.ch[l + 1], d.grp[l], d.hw[l], d.hw[l + 1], d.P[l],
                                      d.K[l], d.ldk[l]};
         a.u = c.at(c.e.U, t);
         a.ldu = d.ld_nin;
-        if (cnn_fwd_supported(a)) return launch_cnn_fwd(a, st);
+        if (c.e.fused_fwd) return launch_cnn_fwd(a, st);
     }
     if (in.obs)
         MARL_TRY(launch_obs_im2col(in.obs, c.at(c.e.COLS[0], t), d.ldk[0], d.R, d.c_img, d.ch[0],
@@ -915,8 +978,8 @@ static int ln_bwd_rank(const Ctx& c, const float* g, int ldg, int kin, int w1, c
                                 c.st);
 }
 
-static int episode_backward(const Ctx& c, const float* g_preds, const float* g_logp,
-                            const float* g_values, float* const* grads) {
+static int episode_backward(const Ctx& c, const void* img, int img_u8, const float* g_preds,
+                            const float* g_logp, const float* g_values, float* const* grads) {
     const Dims& d = c.d;
     hipStream_t st = c.st;
     const int64_t NR = d.NR;
@@ -1207,10 +1270,35 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                                               grads[4 * l + 2], grads[4 * l + 3], 0, st));
             }
             have_dz = false;
-            MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
+            if (c.e.wgrad_ok[l]) {
+                // dW_l (and db_l) from dZ_l and the layer's input, recomputed from what forward
+                // kept (Z_{l-1} + statistics, or the image patch): no im2col rows in HBM
+                CnnWgradArgs w = cnn_wgrad_shape(d, l);
+                w.dz = dz;
+                w.img = img;
+                w.img_u8 = img_u8;
+                w.pos = c.POSs(0);
+                if (l > 0) {
+                    w.zin = c.at(c.e.Z[l - 1], 0);
+                    w.gst = c.at(c.e.GST[l - 1], 0);
+                    w.gamma = c.wp(4 * (l - 1) + 2);
+                    w.beta = c.wp(4 * (l - 1) + 3);
+                } else if (!img) {
+                    set_error("episode_backward: the image batch of the forward call is needed");
+                    return MARL_EINVAL;
+                }
+                const int blocks = cnn_wgrad_blocks(w);
+                w.part_w = c.at(c.e.TNS);
+                w.part_b = w.part_w + (size_t)blocks * co * d.K[l];
+                MARL_TRY(launch_cnn_wgrad(w, st));
+                MARL_TRY(launch_slab_reduce(w.part_w, (int64_t)co * d.K[l], blocks, c.gp(4 * l),
+                                            c.w.ldp[4 * l], co, d.K[l], w.part_b, grads[4 * l + 1], st));
+            } else {
+                MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
+            }
             if (l > 0) {
                 // dZ_l -> dZ_{l-1} in one launch (transposed conv + GroupNorm/SiLU backward)
-                CnnDgradArgs g{};
+                CnnDgradArgs g = cnn_dgrad_shape(d, l);
                 g.dz = dz;
                 g.wt = c.wt(4 * l);
                 g.ldwt = p4(co);
@@ -1220,15 +1308,7 @@ static int episode_backward(const Ctx& c, const float* g_preds, const float* g_l
                 g.beta = c.wp(4 * (l - 1) + 3);
                 g.dzin = c.at(c.e.DZ[l - 1]);
                 g.part = c.at(c.e.PART);
-                g.rows = NR;
-                g.cin = d.ch[l];
-                g.cout = co;
-                g.hin = d.hw[l];
-                g.hout = d.hw[l + 1];
-                g.P = d.P[l];
-                g.Pin = d.P[l - 1];
-                g.G = d.grp[l - 1];
-                if (cnn_dgrad_supported(g) &&
+                if (c.e.dgrad_ok[l] &&
                     (size_t)cnn_dgrad_blocks(g) * 2 * d.ch[l] <= c.e.part_floats) {
                     MARL_TRY(launch_cnn_dgrad(g, st));
                     MARL_TRY(launch_reduce_affine(c.at(c.e.PART), cnn_dgrad_blocks(g), d.ch[l],
@@ -1418,15 +1498,15 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
 }
 
 int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
-                          const float* g_preds, const float* g_logp, const float* g_values,
-                          float* const* grads_host, void* stream) {
+                          const void* img, const float* g_preds, const float* g_logp,
+                          const float* g_values, float* const* grads_host, void* stream) {
     Ctx c;
     MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 1, stream, c));
     if (!grads_host) {
         set_error("episode_backward: null gradient table");
         return MARL_EINVAL;
     }
-    return episode_backward(c, g_preds, g_logp, g_values, grads_host);
+    return episode_backward(c, img, cfg->img_u8 != 0, g_preds, g_logp, g_values, grads_host);
 }
 
 int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float* step_preds,
@@ -1539,7 +1619,13 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
     if (!strcmp(name, "CC")) return set(e.CC + (size_t)t * R * d.ld_na, d.ld_na);
     if (!strcmp(name, "MSG")) return set(e.MSG + (size_t)t * R * d.ld_nm, d.ld_nm);
     if (!strcmp(name, "PROBS")) return set(e.PROBS + (size_t)t * R * d.nA, d.nA);
-    if (!strcmp(name, "COLS0")) return set(e.COLS[0].at(ts), d.ldk[0]);
+    if (!strcmp(name, "COLS0")) {
+        if (e.fused_fwd && (!train || e.wgrad_ok[0])) {
+            set_error("COLS0 is not materialised for this shape (fused CNN kernels)");
+            return MARL_EINVAL;
+        }
+        return set(e.COLS[0].at(e.COLS[0].stride ? ts : 0), d.ldk[0]);
+    }
     if (!strcmp(name, "Z0")) return set(e.Z[0].at(ts), d.ch[1]);
     if (!strcmp(name, "GB")) return set(e.GB.at(ts), d.ld_gb);
     if (train) {

@@ -500,36 +500,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
 }
 
-// Fixed-order reduction of the split-K slabs.  Workgroups past `main_blocks` reduce the
-// column-sum partials instead: one wave per column, lanes strided over the splits.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(
-    const float* __restrict__ part, int64_t split_stride, int splits, float* __restrict__ c,
-    int ldc, int NI, int NJ, const float* __restrict__ csum_part, float* __restrict__ csum_out,
-    int main_blocks) {
-    if ((int)blockIdx.x >= main_blocks) {
-        const int i = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6);
-        if (i >= NI) return;
-        const int lane = threadIdx.x & 63;
-        float s = 0.f;
-        for (int z = lane; z < splits; z += 64) s += csum_part[(size_t)z * NI + i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) csum_out[i] = s;
-        return;
-    }
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)NI * NJ) return;
-    const int i = (int)(idx / NJ), j = (int)(idx % NJ);
+// Fixed-order reduction of partial slabs: out[e] = sum_z part[z * stride + e].  A 1024-thread
+// workgroup owns 64 consecutive elements: wave g sums the slabs z = g, g + 16, ... (four loads in
+// flight), the 16 wave sums meet in LDS and are added in wave order - the same order whatever
+// the grid, so the result is bit-reproducible.  Workgroups past `main_blocks` do the same for
+// the bias partials bpart[z * ni + i].
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(
+    const float* __restrict__ part, int64_t stride, int splits, float* __restrict__ c, int ldc,
+    int NI, int NJ, const float* __restrict__ bpart, float* __restrict__ bias, int main_blocks) {
+    __shared__ float sh[16][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const bool is_bias = (int)blockIdx.x >= main_blocks;
+    const int64_t n = is_bias ? NI : (int64_t)NI * NJ;
+    const int64_t e = (int64_t)(is_bias ? blockIdx.x - main_blocks : blockIdx.x) * 64 + el;
+    const float* src = is_bias ? bpart : part;
+    const int64_t st = is_bias ? NI : stride;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 3 < splits; z += 4) {  // 4 independent loads in flight, fixed order
-        s0 += part[(size_t)z * split_stride + idx];
-        s1 += part[(size_t)(z + 1) * split_stride + idx];
-        s2 += part[(size_t)(z + 2) * split_stride + idx];
-        s3 += part[(size_t)(z + 3) * split_stride + idx];
+    if (e < n) {
+        int z = g;
+        for (; z + 48 < splits; z += 64) {
+            s0 += src[(size_t)z * st + e];
+            s1 += src[(size_t)(z + 16) * st + e];
+            s2 += src[(size_t)(z + 32) * st + e];
+            s3 += src[(size_t)(z + 48) * st + e];
+        }
+        for (; z < splits; z += 16) s0 += src[(size_t)z * st + e];
     }
-    for (; z < splits; ++z) s0 += part[(size_t)z * split_stride + idx];
-    c[(size_t)i * ldc + j] = (s0 + s1) + (s2 + s3);
+    sh[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < n) {
+        float t = sh[0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += sh[q][el];
+        if (is_bias) {
+            bias[e] = t;
+        } else {
+            const int i = (int)(e / NJ), j = (int)(e - (int64_t)i * NJ);
+            c[(size_t)i * ldc + j] = t;
+        }
+    }
+}
+
+int launch_slab_reduce(const float* part, int64_t stride, int splits, float* c, int ldc, int ni,
+                       int nj, const float* bpart, float* bias, hipStream_t st) {
+    const int main_blocks = (int)cdiv((int64_t)ni * nj, 64);
+    const int extra = (bpart && bias) ? (int)cdiv(ni, 64) : 0;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(main_blocks + extra)), dim3(1024), 0, st,
+                       part, stride, splits, c, ldc, ni, nj, bpart, bias, main_blocks);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -815,15 +834,9 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
 #undef MARL_TN_LAUNCH
     prof_after(2, st);
     MARL_LAUNCH_CHECK();
-    if (p.splits > 1) {
-        const int64_t n = (int64_t)ni * nj;
-        const int main_blocks = (int)cdiv(n, 256);
-        const int extra = colsum_out ? (int)cdiv(ni, 4) : 0;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(main_blocks + extra)), dim3(256), 0,
-                           st, scratch, stride, p.splits, c, ldc, ni, nj,
-                           colsum_out ? csum : nullptr, colsum_out, main_blocks);
-        MARL_LAUNCH_CHECK();
-    }
+    if (p.splits > 1)
+        MARL_TRY(launch_slab_reduce(scratch, stride, p.splits, c, ldc, ni, nj,
+                                    colsum_out ? csum : nullptr, colsum_out, st));
     return MARL_OK;
 }
 

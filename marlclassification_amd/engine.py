@@ -164,6 +164,12 @@ class HipEngine:
         self._cfg_key: Optional[Tuple] = None
         self.cfg: Optional[MarlConfig] = None
         self._packed_version: Optional[int] = None
+        # what the last training rollout left behind for backward: the episode workspace holds
+        # its activations, `_fwd_img` keeps its image batch alive (the first convolution's weight
+        # gradient re-gathers the patches), `fwd_generation` lets callers detect a stale backward
+        self.fwd_generation = 0
+        self._fwd_img: Optional[th.Tensor] = None
+        self._fwd_key: Optional[Tuple] = None
 
     # -- configuration / workspaces -------------------------------------------------
     def configure(self, nb_agents: int, batch: int, nb_steps: int, img_shape: Sequence[int],
@@ -245,20 +251,39 @@ class HipEngine:
             cc0.data_ptr(), _ptr(noise), _ptr(forced_actions),
             out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
             out.step_pos.data_ptr(), out.step_actions.data_ptr(), int(train), _stream(dev)))
+        if train:
+            self.fwd_generation += 1
+            self._fwd_img = img
+            self._fwd_key = self._cfg_key
         return out
 
     def episode_backward(
         self, g_preds: Optional[th.Tensor], g_logp: Optional[th.Tensor],
         g_values: Optional[th.Tensor], grads: Dict[str, th.Tensor],
+        generation: Optional[int] = None,
     ) -> None:
+        """Backward of the LAST training rollout.  `generation` (the value of
+        ``fwd_generation`` right after that rollout) makes a stale call fail loudly: the saved
+        activations live in the single training workspace, which a later rollout overwrites."""
         cfg = self.cfg
         assert cfg is not None
+        if self._fwd_img is None or self._fwd_key != self._cfg_key:
+            raise RuntimeError(
+                "episode_backward without a matching training rollout: the engine was "
+                "re-configured (other batch size / image shape) or never ran episode_forward("
+                "train=True) - its workspace no longer holds this episode's activations")
+        if generation is not None and generation != self.fwd_generation:
+            raise RuntimeError(
+                "episode_backward for an episode whose saved activations were overwritten by a "
+                "later training rollout (one live episode per engine: call backward before the "
+                "next run_episode, or accumulate gradients across backward calls instead)")
         gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
         gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
         gv = None if g_values is None else _need(g_values, th.float32, "g_values")
         check(self.lib.marl_episode_backward(
             C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(True).data_ptr(),
-            _ptr(gp), _ptr(gl), _ptr(gv), self._table(grads), _stream(self.device)))
+            self._fwd_img.data_ptr(), _ptr(gp), _ptr(gl), _ptr(gv), self._table(grads),
+            _stream(self.device)))
 
     def a2c_loss(
         self, out: EpisodeTensors, y: th.Tensor, gamma: float, phase: int = 0,
