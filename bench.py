@@ -7,6 +7,11 @@ loss + backward through all steps + Adam [+ RCCL gradient all-reduce]) on the RE
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU; every rank
 works on its own batch shard (weak scaling), gradients are all-reduced over RCCL.
 Prints ONE JSON line on rank 0.
+
+The model is the product's own ``ModelsWrapper`` (reference init recipe), every random draw of
+the episode comes from the library's counter-based generator (no torch kernel in the timed
+loop), and the line is only printed after an untimed post-check of the last iteration
+(finite loss, positions inside the image, actions in range).
 """
 
 from __future__ import annotations
@@ -42,22 +47,75 @@ OTHER = {
            (3, 1024, 1024), 32, "synthetic 1024x1024, 64 agents, 32 steps, f=32"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+# kernel classes of marl_profile_begin (include/marl_hip.h)
+CLASSES = {
+    0: "gemm_nt_kernel<128,128,4,1,LSTM> (belief+action LSTM cells, fused cell epilogue)",
+    1: "gemm_nt_kernel (activations x weights: batched heads, dX / dU products, in-loop W_hh)",
+    2: "gemm_tn_kernel (weight gradients: contraction over all Ns*R rows)",
+    3: "cnn_fwd_kernel (gather + conv/GroupNorm/SiLU stack, one launch per step)",
+    4: "panel_fwd/bwd_kernel (message encoder / decoder, policy hidden layer, per step)",
+    5: "cnn_dgrad + cnn_wgrad kernels (CNN backward, batched over all steps)",
+}
 
 
-def lstm_flops_per_launch(rows: int) -> float:
-    """Algorithmic FLOPs of the fused belief+action LSTM launch:
-    2 * rows * sum over both cells of 4n * (nin + n)."""
-    nf = 64 * 2 * 2
-    nin = nf + C3["n_m_o"] + C3["n_d"]
-    per_row = 2 * (4 * C3["n_b"] * (nin + C3["n_b"]) + 4 * C3["n_a"] * (nin + C3["n_a"]))
-    return float(per_row) * rows
+def cnn_shapes(cfg: dict):
+    """(cin, cout, hin, hout) per conv layer of the feature extractor (networks/vision.py:23-52)."""
+    from marlclassification_amd.engine import CNN_SPECS
+
+    ch, _ = CNN_SPECS[cfg["ft_extr"]]
+    out, h = [], cfg["window"]
+    for ci, co in zip(ch[:-1], ch[1:]):
+        ho = (h - 1) // 2 + 1
+        out.append((ci, co, h, ho))
+        h = ho
+    return out
+
+
+def algorithmic_work(cfg: dict, c_img: int):
+    """Forward FLOPs (2 * MACs of every conv / linear) and compulsory HBM bytes per
+    agent-env-step, as SURVEY section 8(d) defines them, plus the same split by kernel class."""
+    conv = cnn_shapes(cfg)
+    f_cnn = sum(2 * ho * ho * co * 9 * ci for ci, co, _, ho in conv)
+    nf = conv[-1][1] * conv[-1][3] ** 2
+    n_b, n_a, n_m, n_mo, n_d = cfg["n_b"], cfg["n_a"], cfg["n_m"], cfg["n_m_o"], cfg["n_d"]
+    nlb, nla, nC = cfg["nlb"], cfg["nla"], cfg["nb_class"]
+    nA = len(cfg.get("actions", [[1, 0], [-1, 0], [0, 1], [0, -1]]))
+    nin = nf + n_mo + n_d
+    f_lstm = 2 * (4 * n_b * (nin + n_b) + 4 * n_a * (nin + n_a))
+    f_msg = 2 * (n_m * 2 * n_m + 2 * n_m * n_mo) + 2 * (n_b * 2 * n_m + 2 * n_m * n_m)  # decode + encode
+    f_pol_hidden = 2 * n_a * nla
+    f_heads = 2 * (n_a * nla + nla) + 2 * (n_b * nlb + nlb * nC) + 2 * nla * nA  # critic, predict, policy out
+    f_pos = 2 * 2 * n_d
+    fwd = f_cnn + f_lstm + f_msg + f_pol_hidden + f_heads + f_pos
+    c_used = conv[0][0]
+    patch = 4 * c_used * cfg["window"] ** 2
+    by_fwd = patch + 2 * 4 * (2 * n_b + 2 * n_a) + 8 * n_m + 40 + 4 * nA + 4 * (nC + 2) + 16
+    # activations kept for backward, written once + read once (fp32): conv pre-norm outputs and
+    # statistics, U, message nets, gates, head hidden layers
+    saved = (sum(ho * ho * co for _, co, _, ho in conv) + nin + 3 * 2 * n_m + n_m + n_mo + n_d + 4 * n_b
+             + 4 * n_a + 2 * (2 * n_m) + n_m + 3 * nla + 2 * nlb + nA)
+    by_train = by_fwd + 2 * 4 * saved
+    # per kernel class, per agent-env-step, full training iteration (backward = dX + dW products)
+    cls = {
+        0: f_lstm,
+        # NT: batched heads forward + every dX product of backward (the LSTM's dU / dh included)
+        1: (2 * (n_a * nla) + 2 * (n_b * nlb + nlb * nC)) + (2 * nC * nlb + 2 * nlb * n_b + 2 * 2 * nla * n_a)
+           + 2 * (4 * n_b * n_b + 4 * n_a * n_a) + 2 * (4 * n_b + 4 * n_a) * (nin),
+        # TN: every weight gradient outside the CNN
+        2: f_lstm + (2 * 2 * n_a * nla + 2 * nla * nA + 2 * nla) + 2 * (n_b * nlb + nlb * nC) + f_msg + f_pos,
+        3: f_cnn,
+        4: 3 * (f_msg + f_pol_hidden) - f_pol_hidden,  # forward + backward dX (weight grads are class 2)
+        5: 2 * f_cnn,
+    }
+    return fwd, by_fwd, by_train, cls
 
 
 def cpu_baseline(budget_s: float = 25.0) -> dict:
     """The oracle ("port" of the reference's CPU path, incl. its mask + masked_select crop)
     timed on this host's cores on a reduced batch of the same workload (CPU steps/s is
-    batch-independent: SURVEY section 6)."""
+    batch-independent: SURVEY section 6).  Test infrastructure used as the measured CPU leg only."""
     from oracle import marl_oracle as mo
 
     nb = 4
@@ -106,6 +164,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-only", action="store_true")
+    ap.add_argument("--torch-rng", action="store_true",
+                    help="draw positions / states / noise with torch kernels (round-1 behaviour)")
+    ap.add_argument("--graph", action="store_true", help="replay the iteration as a captured hipGraph")
     ap.add_argument("--config", choices=["c3"] + sorted(OTHER), default="c3")
     args = ap.parse_args()
     global C3, NA, NS, IMG
@@ -136,36 +197,47 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from marlclassification_amd import _lib
-    from marlclassification_amd.engine import HipEngine, ModelSpec
-    from marlclassification_amd.fused import FlatParams, FusedA2C, draw_episode
-    from marlclassification_amd.parallel import GradAllReduce, shard_seed
-    from oracle.marl_oracle import OracleConfig, init_params, param_shapes
+    from marlclassification_amd.fused import FusedA2C, draw_episode, draw_episode_device
+    from marlclassification_amd.networks import ModelsWrapper
+    from marlclassification_amd.networks.vision import CNN_BY_NAME
+    from marlclassification_amd.parallel import GradAllReduce, broadcast_parameters, shard_seed
 
     lib = _lib.load()
-    spec = ModelSpec(**C3)
+    actions = C3.get("actions", [[1, 0], [-1, 0], [0, 1], [0, -1]])
+    th.manual_seed(0)  # reference init recipe (networks/init.py), same weights on every rank
+    model = ModelsWrapper(CNN_BY_NAME[C3["ft_extr"]](C3["window"]), C3["n_b"], C3["n_a"], C3["n_m"],
+                          C3["n_m_o"], C3["n_d"], 2, len(actions), C3["nb_class"], C3["nlb"],
+                          C3["nla"]).to(dev)
+    flat = model.flat_state()
+    if distributed:
+        broadcast_parameters(flat.params)
+    eng = model.hip_engine(actions)
+    spec = eng.spec
     is_c3 = args.config == "c3"
-    eng = HipEngine(spec, dev)
     nb = args.batch
     eng.configure(NA, nb, NS, IMG)
-    ocfg = OracleConfig(C3["ft_extr"], C3["window"], C3["n_b"], C3["n_a"], C3["n_m"], C3["n_m_o"],
-                        C3["n_d"], C3["nb_class"], C3["nlb"], C3["nla"],
-                        actions=C3.get("actions", [[1, 0], [-1, 0], [0, 1], [0, -1]]))
-    flat = FlatParams(param_shapes(ocfg), dev)
-    flat.load(init_params(ocfg, 0))  # reference init recipe (networks/init.py), same on all ranks
     hook = GradAllReduce(world) if distributed else None
-    fa = FusedA2C(eng, flat, LR, GAMMA, allreduce=hook)
+    fa = FusedA2C(eng, flat, LR, GAMMA, allreduce=hook, use_graph=args.graph)
 
     gen = th.Generator(device=dev).manual_seed(shard_seed(0, rank))
     img = th.rand(nb, *IMG, device=dev, generator=gen)  # pre-resident in HBM
     y = th.randint(0, C3["nb_class"], (nb,), device=dev, generator=gen)
     egen = th.Generator(device=dev).manual_seed(shard_seed(42, rank))
+    rng_seed = shard_seed(42, rank)
+    state = {"it": 0, "out": None, "scalars": None}
 
     def one_step():
-        draws = draw_episode(spec, NA, nb, NS, IMG[1:], dev, egen)
-        if args.rollout_only:
-            fa.rollout(img, draws, False)
+        if args.torch_rng:
+            draws = draw_episode(spec, NA, nb, NS, IMG[1:], dev, egen)
         else:
-            fa.iteration(img, y, draws)
+            draws = None if args.graph else draw_episode_device(eng, rng_seed, state["it"])
+        if args.rollout_only:
+            state["out"] = fa.rollout(img, draws, False)
+        elif args.graph:
+            state["out"], state["scalars"] = fa.iteration_graph(img, y, rng_seed, state["it"])
+        else:
+            state["out"], state["scalars"] = fa.iteration(img, y, draws)
+        state["it"] += 1
 
     def fence():
         if distributed:
@@ -185,34 +257,85 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    # ---- roofline of the dominant kernel (fused LSTM GEMM), HIP events on its stream ------
-    # Every rank runs the extra iterations (they contain the gradient all-reduce); only rank 0
-    # records events around its LSTM launches.
+    # ---- untimed post-check: a broken kernel must not post a number ------------------------
+    out = state["out"]
+    pos = out.step_pos
+    ok = bool(th.isfinite(out.step_preds).all()) and bool(th.isfinite(out.step_values).all())
+    ok = ok and bool((out.step_log_probas <= 0).all())
+    ok = ok and bool((pos >= 0).all()) and bool((pos[..., 0] + C3["window"] <= IMG[1]).all())
+    ok = ok and bool((pos[..., 1] + C3["window"] <= IMG[2]).all())
+    ok = ok and bool((out.step_actions >= 0).all()) and bool((out.step_actions < len(actions)).all())
+    if state["scalars"] is not None:
+        ok = ok and bool(th.isfinite(state["scalars"]).all())
+        ok = ok and bool(th.isfinite(flat.params).all())
+    if not ok:
+        raise SystemExit("bench post-check failed: non-finite outputs or positions / actions out of range")
+
+    # ---- rooflines ---------------------------------------------------------------------------
+    # (1) whole iteration against both rooflines: algorithmic FLOPs / bytes of the
+    #     timed work vs the fp32-MFMA and HBM peaks; (2) the dominant kernel class, found by a
+    #     per-class HIP-event sweep (one extra iteration per class, events on the launch stream).
+    # Every rank runs the extra iterations (they contain the gradient all-reduce).
     roofline = None
     cpu = None
-    nprof = 3
-    if rank == 0:
-        lib.marl_profile_begin(0, nprof * NS + 8)
-    for _ in range(nprof):
+    f_fwd, by_fwd, by_train, cls_flops = algorithmic_work(C3, IMG[0])
+    steps_per_iter_gpu = nb * NA * NS
+    sweep = {}
+    for c in CLASSES:
+        if args.rollout_only and c in (2, 5):
+            continue
+        if rank == 0:
+            lib.marl_profile_begin(c, 4096)
         one_step()
+        if rank == 0:
+            tot, cnt = C.c_double(0), C.c_int(0)
+            lib.marl_profile_end(C.byref(tot), C.byref(cnt))
+            sweep[c] = (tot.value, cnt.value)
     if rank == 0:
-        tot, cnt = C.c_double(0), C.c_int(0)
-        lib.marl_profile_end(C.byref(tot), C.byref(cnt))
-        avg_s = tot.value / max(1, cnt.value) / 1e3
-        achieved = lstm_flops_per_launch(NA * nb) / avg_s / 1e12 if is_c3 else 0.0
+        t_iter = dt / args.steps
+        mult = 1.0 if args.rollout_only else 3.0
+        flops_iter = mult * f_fwd * steps_per_iter_gpu
+        bytes_iter = (by_fwd if args.rollout_only else by_train) * steps_per_iter_gpu
+        t_mfma = flops_iter / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        t_hbm = bytes_iter / (PEAK_HBM_GBS * 1e9)
+        dom = max(sweep, key=lambda c: sweep[c][0])
+        dom_ms, dom_n = sweep[dom]
+        fwd_only = {0: 1.0, 3: 1.0}  # classes that only run in the rollout
+        dom_flops = cls_flops[dom] * steps_per_iter_gpu
+        if args.rollout_only and dom not in fwd_only:
+            dom_flops /= 3.0
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         roofline = {
-            "kernel": "gemm_nt_kernel<128,128,4,1,LSTM> (belief+action LSTM cells, fused epilogue)",
+            "kernel": CLASSES[dom],
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt.value, "traffic": None,
+            "avg_launch_us": round(dom_ms * 1e3 / max(1, dom_n), 2), "launches": dom_n,
+            "share_of_iteration": round(dom_ms * 1e-3 / t_iter, 4),
+            "traffic": None,
+            "classes": {CLASSES[c].split(" ")[0]: {"ms": round(ms, 3), "launches": n,
+                                                   "tflops": round(cls_flops[c] * steps_per_iter_gpu
+                                                                   / max(ms, 1e-9) / 1e9, 1)}
+                        for c, (ms, n) in sweep.items()},
+            "iteration": {
+                "flops": flops_iter, "bytes": bytes_iter,
+                "t_mfma_ms": round(t_mfma * 1e3, 3), "t_hbm_ms": round(t_hbm * 1e3, 3),
+                "t_measured_ms": round(t_iter * 1e3, 3),
+                "achieved": round(max(t_mfma, t_hbm) / t_iter, 4),
+                "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                "note": "max(t_hbm, t_mfma) / t_measured with algorithmic FLOPs (3x forward) and "
+                        "bytes per agent-env-step from SURVEY 8(d)",
+            },
         }
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
-        # correction + WRITE_SIZE; profiles/r01_lstm_traffic.json says how they were taken)
-        tpath = os.path.join(ROOT, "profiles", "r01_lstm_traffic.json")
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+        # THIS round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if they cover it
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if nb == 256 and is_c3 and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
-                roofline["traffic"] = json.load(f)["traffic_bytes_per_launch"]
-            roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_lstm_traffic.json)"
+                tj = json.load(f)
+            ent = tj.get(str(dom))
+            if ent:
+                roofline["traffic"] = ent["traffic_bytes_per_launch"]
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r02_traffic.json)"
     if distributed:
         dist.barrier()
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
@@ -232,6 +355,8 @@ def main() -> None:
                             "backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
                 "batch_per_gpu": nb, "global_batch": nb * world,
                 "parallelism": f"dp{world}",
+                "rng": "torch" if args.torch_rng else "library (Philox4x32-10)",
+                "launch": "hipGraph replay" if args.graph else "eager",
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -39,6 +39,8 @@ extern "C" {
 #define MARL_EHIP (-3)     /* a HIP runtime call failed                 */
 #define MARL_ESIZE (-4)    /* workspace too small                       */
 
+#define MARL_COUNTERS_BYTES 32 /* device-side counter block, see marl_counters_set */
+
 #define MARL_MAX_CNN_LAYERS 5
 #define MARL_MAX_ACTIONS 16
 
@@ -113,9 +115,42 @@ int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_
                     const int32_t* table_host, int nb_action, int rows,
                     int h, int w, int f, void* stream);
 
+/* Perf-mode draws of one episode inside the library (counter-based Philox4x32-10; same
+ * distributions as the reference's draws - core/environment.py:33-43: pos0[r][d] uniform in
+ * [0, size_d - f); networks/models.py:148-159: h0,c0 [R,n_b], hc0,cc0 [R,n_a] ~ N(0,1) - but not
+ * the reference's mt19937 stream: parity runs inject host-drawn tensors instead).  `noise`
+ * (nullable, [Ns,R,nA]) additionally receives Exp(1) draws.  (seed, offset) selects the stream:
+ * the same pair always produces the same tensors. */
+int marl_draw_episode(const marl_config* cfg, uint64_t seed, uint64_t offset,
+                      const void* counters, int64_t* pos0, float* h0, float* c0, float* hc0,
+                      float* cc0, float* noise, void* stream);
+
+/* Device-resident iteration counters (MARL_COUNTERS_BYTES, caller-owned device memory): the
+ * generator offset of the episode draws and the Adam step with its bias corrections.  Calls that
+ * take `counters` (nullable) ADD its generator offset to their rng_offset argument / take the
+ * Adam step scalars from it, so one iteration (draw -> rollout -> loss -> backward -> Adam ->
+ * re-pack -> marl_counters_tick) can be captured once (marl_graph_*) and replayed with no
+ * host-side change between replays.  set: offset / step (1-based, the step the next Adam applies)
+ * as given; tick: both + 1. */
+int marl_counters_set(void* counters, uint64_t rng_offset, int64_t step, float lr, float beta1,
+                      float beta2, void* stream);
+int marl_counters_tick(void* counters, float lr, float beta1, float beta2, void* stream);
+
+/* hipGraph capture of whatever the library enqueues on `stream` between begin and end (the
+ * stream must not be the NULL stream; nothing may synchronise or allocate in between).
+ * marl_graph_end instantiates the captured graph; marl_graph_launch replays it.  The captured
+ * calls keep their pointer arguments: replays read / write the same buffers. */
+int marl_graph_begin(void* stream);
+int marl_graph_end(void* stream, void** graph_exec_out);
+int marl_graph_launch(void* graph_exec, void* stream);
+int marl_graph_destroy(void* graph_exec);
+
 /* EpisodeSampler.__episode_impl (core/episode.py:32-82) with the reference's random
  * draws as INPUTS: img fp32 (or uint8 when cfg->img_u8) [Nb,C,H,W]; pos0 int64 [R,2]; h0,c0 [R,n_b]; hc0,cc0 [R,n_a];
  * noise [Ns,R,nA] ~ Exp(1) (th.multinomial == argmax(p / noise)).
+ * noise == NULL (and no forced_actions): the Exp(1) variates are drawn inside the sampling
+ * kernel from Philox4x32-10 keyed by (rng_seed, rng_offset, step, row) - perf mode, nothing to
+ * generate, store or read back per step.
  * forced_actions (int64 [Ns,R]) may be NULL; if given it replaces sampling.
  * Outputs: step_preds [Ns,R,nC], step_logp [Ns,R], step_values [Ns,R],
  * step_pos int64 [Ns,R,2] (after move t), step_actions int64 [Ns,R] (may be NULL).
@@ -124,6 +159,7 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
                          const void* img, const int64_t* pos0,
                          const float* h0, const float* c0, const float* hc0, const float* cc0,
                          const float* noise, const int64_t* forced_actions,
+                         uint64_t rng_seed, uint64_t rng_offset, const void* counters,
                          float* step_preds, float* step_logp, float* step_values,
                          int64_t* step_pos, int64_t* step_actions,
                          int train, void* stream);
@@ -154,10 +190,11 @@ int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws,
 
 /* th.optim.Adam.step (training/trainer.py:33,116) on one flat buffer:
  * betas (0.9, 0.999), eps 1e-8, no weight decay; `step` is 1-based. grad_scale
- * multiplies the gradient first (1/world_size after an all-reduce sum). */
+ * multiplies the gradient first (1/world_size after an all-reduce sum).  counters != NULL:
+ * `step` and the bias corrections come from the device-side counter block (graph replay). */
 int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
-                   float grad_scale, void* stream);
+                   float grad_scale, const void* counters, void* stream);
 
 /* ModelsWrapper.forward + MultiAgent.act for ONE step used standalone
  * (networks/models.py:78-138, core/agent.py:40-68): obs [R,C,f,f] is gathered by the
@@ -168,9 +205,11 @@ int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* epis
                       const float* h, const float* c, const float* hc, const float* cc,
                       float* probs, float* values, float* preds, float* new_msg,
                       float* h_out, float* c_out, float* hc_out, float* cc_out,
-                      const float* noise, int64_t* actions_out, float* logp_out, void* stream);
-/* (noise [R,nA] ~ Exp(1), actions_out int64 [R], logp_out [R]: optional - when all three are
- * given the call also samples the action and its log-probability, core/agent.py:53-61.) */
+                      const float* noise, uint64_t rng_seed, uint64_t rng_offset,
+                      int64_t* actions_out, float* logp_out, void* stream);
+/* (actions_out int64 [R], logp_out [R]: optional - when both are given the call also samples the
+ * action and its log-probability, core/agent.py:53-61, from noise [R,nA] ~ Exp(1) if given, else
+ * from the library's generator at (rng_seed, rng_offset).) */
 
 /* Environment.normalized_positions (core/environment.py:74-81): out[r,d] = pos[r,d] / size_d. */
 int marl_normalize_positions(const int64_t* pos, float* out, int rows, int h, int w, void* stream);
@@ -186,9 +225,28 @@ size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows);
 int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta,
                      float* out, int ldo, float* stats, int m, int n, void* stream);
 
+/* Convolution weight gradient from the activations (the kernel behind the conv layers'
+ * dW in marl_episode_backward; backward of networks/vision.py:33-35 for Conv2d(k3,s2,p1)):
+ *   dw[co][tap*cin+ci] = sum over rows r, output positions of dz[r][pos][co] * in[r][window(pos,tap)][ci]
+ * in = the raw patch img[r % nb][:cin][pos[r] + ...] when zin == NULL (first layer), else
+ * SiLU(GroupNorm(zin[r])) with the saved statistics gst[r][G][2] (mean, rstd) and affine.
+ * dz [rows][hout*hout][cout]; zin [rows][hin*hin][cin]; dw [cout][9*cin]; db [cout] = column
+ * sums of dz.  scratch >= marl_cnn_wgrad_scratch() bytes. */
+int marl_cnn_wgrad(const float* dz, const void* img, int img_u8, const int32_t* pos,
+                   const float* zin, const float* gst, const float* gamma, const float* beta,
+                   int64_t rows, int nb, int c_img, int h, int w, int cin, int cout, int hin,
+                   int groups, float* dw, float* db, float* scratch, size_t scratch_bytes,
+                   void* stream);
+size_t marl_cnn_wgrad_scratch(int64_t rows, int cin, int cout, int hin, int groups, int first);
+
+/* Perf-experiment hook: overrides an internal tuning knob (same names as the MARL_<KEY>
+ * environment variables, lower case, e.g. "wgrad_rb"); tools/ and tests only. */
+int marl_tune(const char* key, int value);
+
 /* Measurement hook (bench.py roofline): time every launch of one kernel class with HIP
  * events recorded on the launch stream.  class 0 = fused LSTM-cell GEMM, 1 = plain NT GEMM,
- * 2 = row-contraction (weight-gradient) GEMM.  marl_profile_end synchronises those events
+ * 2 = row-contraction (weight-gradient) GEMM, 3 = fused CNN forward, 4 = row-panel MLP kernels,
+ * 5 = CNN backward (layer backward + weight gradients).  marl_profile_end synchronises those events
  * and returns the summed kernel time and the number of launches seen. */
 int marl_profile_begin(int kernel_class, int max_launches);
 int marl_profile_end(double* total_ms, int* launches);

@@ -55,6 +55,8 @@ def build_parser() -> argparse.ArgumentParser:
     t.add_argument("--res-folder", type=str, dest="res_folder",
                    default=abspath(join(dirname(abspath(__file__)), "..", "resources")))
     t.add_argument("-o", "--output-dir", type=str, required=True, dest="output_dir")
+    t.add_argument("--exact-standardize", action="store_true", dest="exact_standardize",
+                   help="multi-GPU: global advantage statistics (update == single-GPU big batch)")
     return p
 
 
@@ -76,7 +78,7 @@ def main(argv=None) -> None:
             batch_size=args.batch_size, resources_dir=args.res_folder, output_dir=args.output_dir,
             gamma=args.gamma,
         )
-        train_main(main_config, model_config, train_config)
+        train_main(main_config, model_config, train_config, exact_standardize=args.exact_standardize)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ from typing import Optional
 MARL_MAX_CNN_LAYERS = 5
 MARL_MAX_ACTIONS = 16
 MARL_ABI_VERSION = 2
+MARL_COUNTERS_BYTES = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmarl_hip.so")
@@ -66,12 +67,16 @@ EXPORTS = (
     "marl_patch_gather marl_transition marl_episode_forward marl_episode_backward "
     "marl_a2c_loss_fwd_bwd marl_adam_step marl_step_forward marl_gemm_nt marl_gemm_tn "
     "marl_gemm_tn_scratch marl_ln_silu_fwd marl_debug_buffer "
-    "marl_profile_begin marl_profile_end marl_normalize_positions"
+    "marl_profile_begin marl_profile_end marl_normalize_positions "
+    "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_draw_episode "
+    "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
+    "marl_graph_destroy"
 ).split()
 
 _lib: Optional[C.CDLL] = None
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_u64 = C.c_uint64
 _cfgp = C.POINTER(MarlConfig)
 
 
@@ -84,19 +89,33 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_pack_weights.argtypes = [_cfgp, C.POINTER(_vp), _vp, _vp]
     lib.marl_patch_gather.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.marl_transition.argtypes = [_vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _vp]
-    lib.marl_episode_forward.argtypes = [_cfgp, _vp, _vp] + [_vp] * 13 + [_i, _vp]
+    lib.marl_episode_forward.argtypes = ([_cfgp, _vp, _vp] + [_vp] * 8 + [_u64, _u64, _vp] + [_vp] * 5 +
+                                         [_i, _vp])
+    lib.marl_draw_episode.argtypes = [_cfgp, _u64, _u64, _vp] + [_vp] * 7
+    lib.marl_counters_set.argtypes = [_vp, _u64, _i64, _f, _f, _f, _vp]
+    lib.marl_counters_tick.argtypes = [_vp, _f, _f, _f, _vp]
+    lib.marl_graph_begin.argtypes = [_vp]
+    lib.marl_graph_end.argtypes = [_vp, C.POINTER(_vp)]
+    lib.marl_graph_launch.argtypes = [_vp, _vp]
+    lib.marl_graph_destroy.argtypes = [_vp]
     lib.marl_episode_backward.argtypes = [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]
     lib.marl_a2c_loss_fwd_bwd.argtypes = (
         [_cfgp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
     )
-    lib.marl_adam_step.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _vp]
-    lib.marl_step_forward.argtypes = [_cfgp, _vp, _vp] + [_vp] * 15 + [_vp] * 3 + [_vp]
+    lib.marl_adam_step.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _vp, _vp]
+    lib.marl_step_forward.argtypes = ([_cfgp, _vp, _vp] + [_vp] * 15 + [_vp, _u64, _u64, _vp, _vp] +
+                                      [_vp])
     lib.marl_normalize_positions.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     lib.marl_gemm_nt.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.marl_gemm_tn.argtypes = [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i64, _vp, _sz, _vp]
     lib.marl_gemm_tn_scratch.restype = _sz
     lib.marl_gemm_tn_scratch.argtypes = [_i, _i, _i64]
     lib.marl_ln_silu_fwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]
+    lib.marl_cnn_wgrad.argtypes = ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64] + [_i] * 8 +
+                                   [_vp, _vp, _vp, _sz, _vp])
+    lib.marl_cnn_wgrad_scratch.restype = _sz
+    lib.marl_cnn_wgrad_scratch.argtypes = [_i64, _i, _i, _i, _i, _i]
+    lib.marl_tune.argtypes = [C.c_char_p, _i]
     lib.marl_profile_begin.argtypes = [_i, _i]
     lib.marl_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(_i)]
     lib.marl_debug_buffer.argtypes = [_cfgp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]

@@ -23,6 +23,13 @@ class MultiAgent:
         self.__model = model
         self.__hidden: RecurrentOutput | None = None
         self.__last_msg: th.Tensor | None = None
+        # parity hook: a [Na, Nb, nA] tensor of Exp(1) draws used by the NEXT act() instead of
+        # the generator (th.multinomial(p, 1) == argmax(p / q))
+        self.fixed_noise: th.Tensor | None = None
+        # default: the sampling kernel draws its own variates (library generator keyed by torch's
+        # seed and a call counter); False: torch draws the Exp(1) tensor
+        self.device_rng = True
+        self.__calls = 0
 
     def reset(self, batch_size: int) -> None:
         self.__hidden = self.__model.random_first_state(len(self), batch_size)
@@ -38,9 +45,17 @@ class MultiAgent:
                                   observation.shape[4] + 1))
         model.ensure_packed(eng)
         hid = self.__hidden
-        noise = th.empty(na, nb, model.nb_action, device=observation.device).exponential_(1.0)
+        noise, rng = None, None
+        if self.fixed_noise is not None:
+            noise, self.fixed_noise = self.fixed_noise, None
+        elif self.device_rng:
+            rng = (th.initial_seed(), (1 << 40) + self.__calls)  # offsets apart from the episodes'
+            self.__calls += 1
+        else:
+            noise = th.empty(na, nb, model.nb_action, device=observation.device).exponential_(1.0)
         probs, values, preds, msg, h, c, hc, cc, actions, logp = eng.step_forward(
-            observation, self.__last_msg, norm_pos, hid.h, hid.c, hid.h_caret, hid.c_caret, noise)
+            observation, self.__last_msg, norm_pos, hid.h, hid.c, hid.h_caret, hid.c_caret, noise,
+            rng=rng)
         self.__hidden = RecurrentOutput(h, c, hc, cc)
         self.__last_msg = msg
         return AgentOutput(actions=actions, actions_log_probs=logp, predictions=preds, values=values)

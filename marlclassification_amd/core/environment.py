@@ -4,7 +4,7 @@ core/environment.py).  Same public surface; the crop and the bounded move are HI
 masked_select; ``marl_transition``).  Inside ``EpisodeSampler`` none of these methods is
 called per step - the fused episode keeps positions on the device."""
 
-from typing import List
+from typing import List, Optional
 
 import torch as th
 
@@ -25,13 +25,18 @@ class Environment:
         self.place(img_batch, nb_agents)
         return self.observe()
 
-    def place(self, img_batch: th.Tensor, nb_agents: int) -> th.Tensor:
-        """reset() without the observation gather (what the fused episode needs)."""
+    def place(self, img_batch: th.Tensor, nb_agents: int,
+              positions: Optional[th.Tensor] = None) -> th.Tensor:
+        """reset() without the observation gather (what the fused episode needs).
+        ``positions`` ([Na, Nb, 2] int64): use these instead of drawing (parity / device RNG)."""
         if img_batch.dim() != 4:
             raise ValueError("expected an image batch [Nb, C, H, W]")
         self.__img_batch = img_batch
         self.__img_sizes = list(img_batch.shape[2:])
         batch = img_batch.shape[0]
+        if positions is not None:
+            self.__pos = positions
+            return self.__pos
         self.__pos = th.stack(
             [th.randint(s - self.__window_size, (nb_agents, batch), device=img_batch.device)
              for s in self.__img_sizes],

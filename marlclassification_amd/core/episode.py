@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 import torch as th
 
 from ..engine import EpisodeTensors, HipEngine
-from ..fused import EpisodeDraws
+from ..fused import EpisodeDraws, draw_episode_device
 from .agent import MultiAgent
 from .environment import Environment
 
@@ -36,7 +36,7 @@ class _EpisodeFunction(th.autograd.Function):
     @staticmethod
     def forward(ctx, eng: HipEngine, img: th.Tensor, draws: EpisodeDraws, names, *params):
         out = eng.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0, draws.cc0,
-                                  draws.noise, None, True)
+                                  draws.noise, None, True, rng=draws.rng)
         ctx.eng = eng
         ctx.generation = eng.fwd_generation  # the workspace holds THIS episode until the next one
         ctx.names = names
@@ -60,6 +60,12 @@ class EpisodeSampler:
         # parity hook: when set, these draws replace the random ones (tests inject the
         # reference's host-drawn positions / states / noise)
         self.fixed_draws: Optional[EpisodeDraws] = None
+        # perf mode (default): every draw comes from the library's counter-based generator, keyed
+        # by torch's seed (th.manual_seed keeps runs reproducible) and an episode counter.  False:
+        # torch draws in the reference's order (positions, h, c, h^, c^, per-step Exp(1)).
+        self.device_rng = True
+        self.__episodes = 0
+        self.__rng_seed: Optional[int] = None
 
     @property
     def nb_step(self) -> int:
@@ -86,9 +92,18 @@ class EpisodeSampler:
         # uint8 batches ([Nb,C,H,W], 0..255) stay uint8: ToTensor happens inside the gather kernel
         eng.configure(na, nb, ns, img.shape[1:], img_u8=img.dtype == th.uint8)
         model.ensure_packed(eng)
-        pos0 = env.place(img, na)
         if self.fixed_draws is not None:
+            env.place(img, na, positions=self.fixed_draws.pos0)
             return eng, img, self.fixed_draws
+        if self.device_rng:
+            seed = th.initial_seed()
+            if seed != self.__rng_seed:  # th.manual_seed() restarts the episode counter
+                self.__rng_seed, self.__episodes = seed, 0
+            d = draw_episode_device(eng, seed, self.__episodes)
+            self.__episodes += 1
+            env.place(img, na, positions=d.pos0)
+            return eng, img, d
+        pos0 = env.place(img, na)
         st = model.random_first_state(na, nb)
         noise = th.empty(ns, na, nb, env.nb_actions, device=device).exponential_(1.0)
         return eng, img, EpisodeDraws(pos0, st.h, st.c, st.h_caret, st.c_caret, noise)
@@ -103,7 +118,7 @@ class EpisodeSampler:
                 eng, img, draws, names, *[p for _, p in named])
         else:
             out = eng.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0, draws.cc0,
-                                      draws.noise, None, False)
+                                      draws.noise, None, False, rng=draws.rng)
             preds, logp, values, pos = (out.step_preds, out.step_log_probas, out.step_values,
                                         out.step_pos)
         self.__env._set_positions(pos[-1])
@@ -123,6 +138,7 @@ class EpisodeSampler:
         eng, img, d = self.prepare(img_batch)
         if draws is not None:
             d = draws
-        out = eng.episode_forward(img, d.pos0, d.h0, d.c0, d.hc0, d.cc0, d.noise, None, train)
+        out = eng.episode_forward(img, d.pos0, d.h0, d.c0, d.hc0, d.cc0, d.noise, None, train,
+                                  rng=d.rng)
         self.__env._set_positions(out.step_pos[-1])
         return eng, out

@@ -447,7 +447,9 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
     const int rec = ts_begin(&d_ts, calls++);
     a.ts = rec ? d_ts : nullptr;
 #endif
+    prof_before(3, st);
     hipLaunchKernelGGL(cnn_fwd_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
+    prof_after(3, st);
     MARL_LAUNCH_CHECK();
 #ifdef MARL_KERNEL_TS
     if (rec) ts_report("cnn_fwd", d_ts, 8);
@@ -839,7 +841,9 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
     ++calls;
     a.ts = rec ? d_ts : nullptr;
 #endif
+    prof_before(5, st);
     hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
+    prof_after(5, st);
     MARL_LAUNCH_CHECK();
 #ifdef MARL_KERNEL_TS
     if (rec) {
@@ -864,11 +868,10 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
 // Wave roles: (cout-tile group, k-tile group, row-step phase); waves that share tiles but walk
 // different row steps are summed through LDS once at the end.
 // ---------------------------------------------------------------------------
-constexpr int kWgPD = 4;   // prefetched float4 of dZ per thread
-constexpr int kWgPZ = 4;   // prefetched float4 of Z_{l-1} per thread
-constexpr int kWgPR = 14;  // prefetched raw pixels per thread (first layer)
-
-template <int NCT, int NKT, bool FIRST>
+// PD = float4 of dZ prefetched per thread; PI = prefetched input items per thread (float4 of
+// Z_{l-1}, or raw pixels for the first layer).  Small values keep the kernel under 128 VGPRs so
+// that two workgroups share a CU and hide each other's staging phases.
+template <int NCT, int NKT, bool FIRST, int PD, int PI>
 __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* In = lds;                                       // [rb][hp][hp][cs]
@@ -919,27 +922,61 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
         tab[m] = lr * in_per + (2 * oy * hp + 2 * ox) * cs;
     }
 
-    // ---- staging roles (fixed per thread: 512 is a multiple of cout / 4 and of cin / 4)
-    const int c4o = cout >> 2, c4i = cin >> 2;
+    // ---- staging roles: everything that does not depend on the chunk is worked out once
+    // (512 is a multiple of cout / 4 and of cin / 4, so a thread keeps its channels)
+    const int c4o = cout >> 2;
     const int dz_c = (tid % c4o) * 4, dz_m0 = tid / c4o, dz_mstep = 512 / c4o;
-    const int zi_c = FIRST ? 0 : (tid % c4i) * 4, zi_p0 = FIRST ? 0 : tid / c4i,
-              zi_pstep = FIRST ? 1 : 512 / c4i;
+    const int Pin = A.hin * A.hin;
+    // input items of this thread: patch-in-chunk, LDS float offset, global offset inside the
+    // patch's source (image plane offset for the first layer, Z_{l-1} element otherwise)
+    int it_lr[PI], it_lo[PI], it_go[PI];
     float4 gm4 = make_float4(0.f, 0.f, 0.f, 0.f), bt4 = gm4;
     int zi_g = 0;
-    if (!FIRST) {
+    if (FIRST) {
+        const int ff = Pin, pe = cin * ff;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int idx = tid + i * 512;
+            it_lr[i] = -1;
+            it_lo[i] = it_go[i] = 0;
+            if (idx < rb * pe) {
+                const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
+                const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
+                const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
+                it_lr[i] = lr;
+                it_lo[i] = lr * in_per + ((iy + 1) * hp + ix + 1) * cs + ci;
+                it_go[i] = (ci * A.H + iy) * A.W + ix;
+            }
+        }
+    } else {
+        const int c4i = cin >> 2;
+        const int zi_c = (tid % c4i) * 4, zi_p0 = tid / c4i, zi_pstep = 512 / c4i;
         gm4 = *reinterpret_cast<const float4*>(A.gamma + zi_c);
         bt4 = *reinterpret_cast<const float4*>(A.beta + zi_c);
         zi_g = zi_c / (cin / A.G);
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int pl = zi_p0 + i * zi_pstep;  // patch-major input position
+            it_lr[i] = -1;
+            it_lo[i] = it_go[i] = 0;
+            if (pl < rb * Pin) {
+                const int lr = fdiv(pl, A.dPin), ipos = pl - lr * Pin;
+                const int iy = fdiv(ipos, A.dhin), ix = ipos - iy * A.hin;
+                it_lr[i] = lr;
+                it_lo[i] = lr * in_per + ((iy + 1) * hp + ix + 1) * cs + zi_c;
+                it_go[i] = pl * cin + zi_c;
+            }
+        }
     }
-    const int Pin = A.hin * A.hin;
-    const int ff = A.hin * A.hin, pe = cin * ff;   // first layer: hin = f
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 pd[kWgPD], pz[kWgPZ];
-    float2 ps[kWgPZ];
-    float pr[kWgPR];
+    float4 pd[PD];
+    float4 pz[FIRST ? 1 : PI];
+    float2 ps[FIRST ? 1 : PI];
+    float pr[FIRST ? PI : 1];
     const float* imgf = static_cast<const float*>(A.img);
     const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+    const int64_t plane = (int64_t)A.c_img * A.H * A.W;
 
     auto prefetch = [&](int chunk) {
         const int64_t row0 = (int64_t)chunk * rb;
@@ -947,37 +984,31 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
         const int M = nrow * P;
         const float* dsrc = A.dz + row0 * P * (int64_t)cout + dz_c;
 #pragma unroll
-        for (int i = 0; i < kWgPD; ++i) {
+        for (int i = 0; i < PD; ++i) {
             const int m = dz_m0 + i * dz_mstep;
             pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) pd[i] = *reinterpret_cast<const float4*>(dsrc + (int64_t)m * cout);
         }
         if (FIRST) {
 #pragma unroll
-            for (int i = 0; i < kWgPR; ++i) {
-                const int idx = tid + i * 512;
+            for (int i = 0; i < PI; ++i) {
                 pr[i] = 0.f;
-                if (idx < nrow * pe) {
-                    const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
-                    const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
-                    const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
-                    const int64_t r = row0 + lr;
+                if ((unsigned)it_lr[i] < (unsigned)nrow) {
+                    const int64_t r = row0 + it_lr[i];
                     const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
-                    const int64_t off = (((r % A.nb) * A.c_img + ci) * (int64_t)A.H + (p0 + iy)) * A.W + (p1 + ix);
+                    const int64_t off = (r % A.nb) * plane + (int64_t)p0 * A.W + p1 + it_go[i];
                     pr[i] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
                 }
             }
         } else {
-            const float* zsrc = A.zin + row0 * Pin * (int64_t)cin + zi_c;
+            const float* zsrc = A.zin + row0 * Pin * (int64_t)cin;
 #pragma unroll
-            for (int i = 0; i < kWgPZ; ++i) {
-                const int pl = zi_p0 + i * zi_pstep;  // patch-major input position
+            for (int i = 0; i < PI; ++i) {
                 pz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 ps[i] = make_float2(0.f, 0.f);
-                if (pl < nrow * Pin) {
-                    pz[i] = *reinterpret_cast<const float4*>(zsrc + (int64_t)pl * cin);
-                    const int lr = fdiv(pl, A.dPin);
-                    ps[i] = *reinterpret_cast<const float2*>(A.gst + ((row0 + lr) * A.G + zi_g) * 2);
+                if ((unsigned)it_lr[i] < (unsigned)nrow) {
+                    pz[i] = *reinterpret_cast<const float4*>(zsrc + it_go[i]);
+                    ps[i] = *reinterpret_cast<const float2*>(A.gst + ((row0 + it_lr[i]) * A.G + zi_g) * 2);
                 }
             }
         }
@@ -986,7 +1017,7 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
         const int64_t row0 = (int64_t)chunk * rb;
         const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
 #pragma unroll
-        for (int i = 0; i < kWgPD; ++i) {
+        for (int i = 0; i < PD; ++i) {
             const int m = dz_m0 + i * dz_mstep;
             if (m < Mpad) {  // rows past this chunk's M hold zeros (they multiply stale inputs)
                 *reinterpret_cast<float4*>(Dz + m * zs + dz_c) = pd[i];
@@ -998,29 +1029,19 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
         }
         if (FIRST) {
 #pragma unroll
-            for (int i = 0; i < kWgPR; ++i) {
-                const int idx = tid + i * 512;
-                if (idx < nrow * pe) {
-                    const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
-                    const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
-                    const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
-                    In[lr * in_per + ((iy + 1) * hp + ix + 1) * cs + ci] = pr[i];
-                }
-            }
+            for (int i = 0; i < PI; ++i)
+                if ((unsigned)it_lr[i] < (unsigned)nrow) In[it_lo[i]] = pr[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < kWgPZ; ++i) {
-                const int pl = zi_p0 + i * zi_pstep;
-                if (pl < nrow * Pin) {
-                    const int lr = fdiv(pl, A.dPin), ipos = pl - lr * Pin;
-                    const int iy = fdiv(ipos, A.dhin), ix = ipos - iy * A.hin;
+            for (int i = 0; i < PI; ++i) {
+                if ((unsigned)it_lr[i] < (unsigned)nrow) {
                     const float mean = ps[i].x, rstd = ps[i].y;
                     float4 v;
                     v.x = cnn_silu((pz[i].x - mean) * rstd * gm4.x + bt4.x);
                     v.y = cnn_silu((pz[i].y - mean) * rstd * gm4.y + bt4.y);
                     v.z = cnn_silu((pz[i].z - mean) * rstd * gm4.z + bt4.z);
                     v.w = cnn_silu((pz[i].w - mean) * rstd * gm4.w + bt4.w);
-                    *reinterpret_cast<float4*>(In + lr * in_per + ((iy + 1) * hp + ix + 1) * cs + zi_c) = v;
+                    *reinterpret_cast<float4*>(In + it_lo[i]) = v;
                 }
             }
         }
@@ -1035,20 +1056,40 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
         if (chunk + (int)gridDim.x < A.nchunks) prefetch(chunk + gridDim.x);
         const int64_t row0 = (int64_t)chunk * rb;
         const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
-        const int msteps = (nrow * P + 3) >> 2;
-        for (int s = ms_id; s < msteps; s += ms) {
-            const int m = s * 4 + quad;
-            const int rbase = tab[m];
+        const int msteps = (nrow * P + 3) >> 2, last = msteps - 1;
+        // software-pipelined row steps: the fragments of step s + ms (and the row-table entry of
+        // step s + 2 ms) are read while the matrix instructions of step s issue
+        int s = ms_id;
+        if (s < msteps) {
             float a[NCT], b[NKT];
+            int rb2;
+            {
+                const int m = s * 4 + quad;
+                const int rb1 = tab[m];
+                rb2 = tab[min(s + ms, last) * 4 + quad];
 #pragma unroll
-            for (int i = 0; i < NCT; ++i) a[i] = Dz[m * zs + aoff[i]];
+                for (int i = 0; i < NCT; ++i) a[i] = Dz[m * zs + aoff[i]];
 #pragma unroll
-            for (int j = 0; j < NKT; ++j) b[j] = In[rbase + toff[j]];
+                for (int j = 0; j < NKT; ++j) b[j] = In[rb1 + toff[j]];
+            }
+            for (; s < msteps; s += ms) {
+                float an[NCT], bn[NKT];
+                const int mn = min(s + ms, last) * 4 + quad;
 #pragma unroll
-            for (int j = 0; j < NKT; ++j)
+                for (int i = 0; i < NCT; ++i) an[i] = Dz[mn * zs + aoff[i]];
 #pragma unroll
-                for (int i = 0; i < NCT; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NKT; ++j) bn[j] = In[rb2 + toff[j]];
+                rb2 = tab[min(s + 2 * ms, last) * 4 + quad];
+#pragma unroll
+                for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NCT; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NCT; ++i) a[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) b[j] = bn[j];
+            }
         }
     }
 
@@ -1109,12 +1150,17 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
     }
 }
 
+// prefetch depths the kernel is instantiated with: {dZ float4, input items} per thread
+static const int kWgPref[2][2][2] = {{{2, 2}, {4, 4}},    // deeper layers (float4 of Z_{l-1})
+                                     {{2, 4}, {4, 14}}};  // first layer (raw pixels)
+
 // picks the wave roles and the chunk size; returns the dynamic LDS floats (0 = unsupported)
 static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
     if ((a.cout & 3) || 512 % (a.cout / 4) != 0 || a.cout > 2048) return 0;
     if (!a.first && ((a.cin & 3) || 512 % (a.cin / 4) != 0 || a.cin % a.G != 0 || ((a.cin / a.G) & 3)))
         return 0;
     if (a.hin > 200 || a.rows <= 0) return 0;
+    if (a.first && (int64_t)a.c_img * a.H * a.W >= (1ll << 31)) return 0;
     a.nct = (a.cout + 15) / 16;
     a.nkt = (a.K + 15) / 16;
     // tile slabs over grid.y when one workgroup (8 waves x <= 18 tile slots) cannot hold them all
@@ -1164,45 +1210,45 @@ static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
     a.dpe = make_fdiv(a.cin * a.hin * a.hin);
     a.dff = make_fdiv(a.hin * a.hin);
     a.df = make_fdiv(a.hin);
-    static int lds_cap_kb = 0, rb_cap = 0;
-    if (!lds_cap_kb) {
-        const char* e = getenv("MARL_WGRAD_LDS_KB");
-        lds_cap_kb = e ? atoi(e) : 76;
-        const char* r = getenv("MARL_WGRAD_RB");
-        rb_cap = r ? atoi(r) : 16;
-        if (rb_cap < 1) rb_cap = 1;
-    }
+    const int lds_cap_kb = tune_get("wgrad_lds_kb", 76);
+    int rb_cap = tune_get("wgrad_rb", 16);
+    if (rb_cap < 1) rb_cap = 1;
+    const int wg_per_cu = tune_get("wgrad_wgs", 0);  // 0 = by layer size
     const size_t red = a.ms > 1 ? (size_t)8 * bct * bkt * 256 : 0;
-    for (int rb = rb_cap; rb >= 1; --rb) {
-        const int M = rb * a.P, Mpad = (M + 3) & ~3;
-        if ((int64_t)M * a.cout > (int64_t)kWgPD * 512 * 4) continue;
-        if (a.first ? (int64_t)rb * a.cin * a.hin * a.hin > (int64_t)kWgPR * 512
-                    : (int64_t)rb * a.hin * a.hin * a.cin > (int64_t)kWgPZ * 512 * 4)
-            continue;
-        size_t off = ((size_t)rb * a.in_per + 3) & ~(size_t)3;
-        const size_t off_dz = off;
-        off += (size_t)Mpad * a.zs;
-        const size_t off_tab = off;
-        off += Mpad;
-        size_t tot = off > red ? off : red;
-        if (tot < 2048) tot = 2048;  // bias reduction scratch
-        if (tot * sizeof(float) > (size_t)lds_cap_kb * 1024 && rb > 1) continue;
-        if (tot * sizeof(float) > 150 * 1024) return 0;
-        a.rb = rb;
-        a.off_dz = (int)off_dz;
-        a.off_tab = (int)off_tab;
-        a.lds_floats = (int)tot;
-        a.nchunks = (int)cdiv(a.rows, rb);
-        static int wg_per_cu = 0;
-        if (!wg_per_cu) {
-            const char* e = getenv("MARL_WGRAD_WGS");
-            wg_per_cu = e ? atoi(e) : 2;
-            if (wg_per_cu < 1) wg_per_cu = 1;
+    // the shallow prefetch variant first (fewer registers -> two workgroups per CU)
+    for (int v = 0; v < 2; ++v) {
+        const int PD = kWgPref[a.first ? 1 : 0][v][0], PI = kWgPref[a.first ? 1 : 0][v][1];
+        for (int rb = rb_cap; rb >= 1; --rb) {
+            const int M = rb * a.P, Mpad = (M + 3) & ~3;
+            if ((int64_t)M * a.cout > (int64_t)PD * 512 * 4) continue;
+            if (a.first ? (int64_t)rb * a.cin * a.hin * a.hin > (int64_t)PI * 512
+                        : (int64_t)rb * a.hin * a.hin * a.cin > (int64_t)PI * 512 * 4)
+                continue;
+            size_t off = ((size_t)rb * a.in_per + 3) & ~(size_t)3;
+            const size_t off_dz = off;
+            off += (size_t)Mpad * a.zs;
+            const size_t off_tab = off;
+            off += Mpad;
+            size_t tot = off > red ? off : red;
+            if (tot < 2048) tot = 2048;  // bias reduction scratch
+            if (tot * sizeof(float) > (size_t)lds_cap_kb * 1024 && rb > 1) continue;
+            if (tot * sizeof(float) > 150 * 1024) break;
+            a.rb = rb;
+            a.pd = PD;
+            a.pi = PI;
+            a.off_dz = (int)off_dz;
+            a.off_tab = (int)off_tab;
+            a.lds_floats = (int)tot;
+            a.nchunks = (int)cdiv(a.rows, rb);
+            // persistent workgroups: an upper bound here (it sizes the partial-slab scratch); the
+            // launcher trims it to what is actually resident.  Small layers are staging-bound and
+            // want more workgroups per CU in flight, their slabs are small.
+            const int per_cu = wg_per_cu > 0 ? wg_per_cu : ((int64_t)a.cout * a.K <= 8192 ? 4 : 2);
+            int blocks = 256 * per_cu / a.slabs;
+            if (blocks < 64) blocks = 64;
+            a.blocks = a.nchunks < blocks ? a.nchunks : blocks;
+            return tot;
         }
-        int blocks = 256 * wg_per_cu / a.slabs;
-        if (blocks < 64) blocks = 64;
-        a.blocks = a.nchunks < blocks ? a.nchunks : blocks;
-        return tot;
     }
     return 0;
 }
@@ -1219,9 +1265,9 @@ int cnn_wgrad_blocks(const CnnWgradArgs& a0) {
     return cnn_wgrad_plan(a) > 0 ? a.blocks : 0;
 }
 
-template <int NCT, int NKT, bool FIRST>
+template <int NCT, int NKT, bool FIRST, int PD, int PI>
 static int wgrad_launch(const CnnWgradArgs& a, size_t lds, hipStream_t st) {
-    auto kern = cnn_wgrad_kernel<NCT, NKT, FIRST>;
+    auto kern = cnn_wgrad_kernel<NCT, NKT, FIRST, PD, PI>;
     if (lds > 64 * 1024) {
         static bool raised = false;  // per process; one process drives one GPU (see marl_hip.h)
         if (!raised) {
@@ -1230,12 +1276,34 @@ static int wgrad_launch(const CnnWgradArgs& a, size_t lds, hipStream_t st) {
             raised = true;
         }
     }
+    prof_before(5, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)a.blocks, (unsigned)a.slabs), dim3(512), lds, st, a);
+    prof_after(5, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
 
+// resident workgroups per CU of one instantiation at this LDS size (registers, LDS, wave slots)
+template <int NCT, int NKT, bool FIRST, int PD, int PI>
+static int wgrad_occupancy(size_t lds) {
+    static size_t seen_lds[8];  // (the same instantiation serves layers with different LDS sizes)
+    static int seen_occ[8], nseen = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen_lds[i] == lds) return seen_occ[i];
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &occ, reinterpret_cast<const void*>(cnn_wgrad_kernel<NCT, NKT, FIRST, PD, PI>), 512, lds) !=
+            hipSuccess || occ < 1)
+        occ = 1;
+    if (nseen < 8) {
+        seen_lds[nseen] = lds;
+        seen_occ[nseen++] = occ;
+    }
+    return occ;
+}
+
 int launch_cnn_wgrad(CnnWgradArgs& a, hipStream_t st) {
+    float* part_w = a.part_w;
     const size_t fl = cnn_wgrad_plan(a);
     if (!fl) {
         set_error("conv weight gradient: shape outside the fused kernel's range");
@@ -1243,12 +1311,30 @@ int launch_cnn_wgrad(CnnWgradArgs& a, hipStream_t st) {
     }
     const size_t lds = fl * sizeof(float);
     const int sct = a.sct, skt = a.skt;
-#define MARL_WG(CT, KT)                                                        \
-    if (sct == CT && skt == KT)                                                \
-        return a.first ? wgrad_launch<1, (KT <= 3 ? KT : 1), true>(a, lds, st) \
-                       : wgrad_launch<CT, KT, false>(a, lds, st);
+    const bool deep = a.pd == 4;
+    // grid = what is resident at once (a persistent workgroup that has to wait for a slot only
+    // lengthens the tail); never more than the bound the scratch was sized for
+#define MARL_WG_GO(...)                                                                          \
+    {                                                                                            \
+        const int occ_ = wgrad_occupancy<__VA_ARGS__>(lds);                                      \
+        int res_ = 256 * occ_ / a.slabs;                                                         \
+        if (res_ < 64) res_ = 64;                                                                \
+        if (res_ < a.blocks) a.blocks = res_;                                                    \
+        a.part_b = part_w + (size_t)a.blocks * a.cout * a.K;                                     \
+        return wgrad_launch<__VA_ARGS__>(a, lds, st);                                            \
+    }
+#define MARL_WG(CT, KT)                                                                          \
+    if (sct == CT && skt == KT) {                                                                \
+        if (a.first) {                                                                           \
+            if (deep) MARL_WG_GO(1, (KT <= 3 ? KT : 1), true, 4, 14)                             \
+            MARL_WG_GO(1, (KT <= 3 ? KT : 1), true, 2, 4)                                        \
+        }                                                                                        \
+        if (deep) MARL_WG_GO(CT, KT, false, 4, 4)                                                \
+        MARL_WG_GO(CT, KT, false, 2, 2)                                                          \
+    }
     MARL_WG(1, 1) MARL_WG(1, 2) MARL_WG(1, 3) MARL_WG(1, 5) MARL_WG(1, 9) MARL_WG(2, 5) MARL_WG(2, 9)
 #undef MARL_WG
+#undef MARL_WG_GO
     set_error("conv weight gradient: no kernel for tile shape %d x %d", sct, skt);
     return MARL_ELIMIT;
 }

@@ -16,6 +16,11 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 void set_error(const char* fmt, ...);
 
+// Tuning knobs (perf experiments, tests): value set by marl_tune(), else the environment variable
+// MARL_<KEY IN UPPER CASE>, else `dflt`.  Read at every launch - cheap, host side only.
+int tune_get(const char* key, int dflt);
+int tune_set(const char* key, int value);
+
 // Sum over the 64 lanes of a wave on the VALU (DPP row shifts + row broadcasts, then a
 // readlane of lane 63): no LDS-pipe ds_bpermute round trips, result is wave-uniform.
 // Call with all 64 lanes active.
@@ -113,6 +118,10 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st);
 // LSTM cell: gates = seg products + bias over 4*n_units rows of B, then the cell update.
 int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st);
 
+// per-launch HIP-event timing of one kernel class (see marl_profile_begin); no-ops when off
+constexpr int kProfClasses = 6;
+void prof_before(int cls, hipStream_t st);
+void prof_after(int cls, hipStream_t st);
 int profile_begin(int cls, int max_launches);
 int profile_end(double* total_ms, int* launches);
 
@@ -185,7 +194,11 @@ struct SampleArgs {
     const float* w1;  // packed [nA, ldw]
     int ldw;
     const float* b1;
-    const float* noise;            // [R, nA]
+    const float* noise;            // [R, nA] injected Exp(1) draws (parity mode), or null
+    uint64_t rng_seed, rng_ctr;    // noise == null: Exp(1) drawn in-kernel, Philox4x32-10 keyed by
+                                   // rng_seed at counter (rng_ctr, row, action / 4)
+    const uint64_t* rng_off_dev;   // optional device-side offset (counter block), added << 16
+    int rng_on;
     const int64_t* forced;         // [R] or null
     const int32_t* pos_in;         // [R, 2]
     int32_t* pos_out;              // [R, 2]
@@ -209,6 +222,14 @@ struct SampleArgs {
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 
+// Perf-mode episode draws (the reference's reset draws, core/environment.py:33-43 and
+// networks/models.py:148-159, from a counter-based generator): pos0[r][d] uniform in
+// [0, size_d - f), h0 / c0 [R, n_b] and hc0 / cc0 [R, n_a] standard normal, optionally the
+// per-step Exp(1) noise [Ns * R * nA].
+int launch_draw_episode(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* pos0,
+                        int R, int H, int W, int f, float* h0, float* c0, int n_b, float* hc0,
+                        float* cc0, int n_a, float* noise, int64_t n_noise, hipStream_t st);
+
 // generic permuted copies used by pack / unpack
 struct PermDesc {
     const float* src;
@@ -226,9 +247,25 @@ struct PermBatch {
 };
 int launch_permute(const PermBatch& b, hipStream_t st);
 
+// Device-resident per-iteration counters (marl_counters_* in marl_hip.h): what changes from one
+// training iteration to the next WITHOUT host involvement, so that a captured hipGraph can be
+// replayed unchanged - the generator offset of the episode draws and the Adam step with its bias
+// corrections.
+struct Counters {
+    uint64_t rng_offset;
+    uint64_t step;        // optimiser steps done so far + 1 = the step the NEXT adam launch applies
+    float lr_over_bc1;    // lr / (1 - beta1^step)
+    float inv_sqrt_bc2;   // 1 / sqrt(1 - beta2^step)
+    float pad[2];
+};
+static_assert(sizeof(Counters) == MARL_COUNTERS_BYTES, "counter block layout");
+int launch_counters_set(Counters* c, uint64_t rng_offset, int64_t step, float lr, float beta1,
+                        float beta2, int tick, hipStream_t st);
+
+// cnt != null: step size and bias correction come from the counter block instead
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_over_bc1,
                 float inv_sqrt_bc2, float beta1, float beta2, float eps, float grad_scale,
-                hipStream_t st);
+                hipStream_t st, const Counters* cnt = nullptr);
 
 // elementwise helpers
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
@@ -463,6 +500,7 @@ struct CnnWgradArgs {
     int nct, nkt, nkt_slab, slabs;  // 16-wide tiles of cout / K, k tiles per grid.y slab
     int tgc, tgk, ms;             // wave roles: cout-tile groups x k-tile groups x row-step interleave
     int sct, skt;                 // accumulator tiles per wave (template shape of the launch)
+    int pd, pi;                   // prefetch depth per thread (template shape of the launch)
     FDiv dP, dhout, dPin, dhin, dcin, dc4o, dc4i, dpe, dff, df;
 };
 int cnn_wgrad_supported(const CnnWgradArgs& a);

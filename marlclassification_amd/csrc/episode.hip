@@ -1287,11 +1287,9 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
                     set_error("episode_backward: the image batch of the forward call is needed");
                     return MARL_EINVAL;
                 }
-                const int blocks = cnn_wgrad_blocks(w);
-                w.part_w = c.at(c.e.TNS);
-                w.part_b = w.part_w + (size_t)blocks * co * d.K[l];
+                w.part_w = c.at(c.e.TNS);  // the launcher places part_b behind the weight slabs
                 MARL_TRY(launch_cnn_wgrad(w, st));
-                MARL_TRY(launch_slab_reduce(w.part_w, (int64_t)co * d.K[l], blocks, c.gp(4 * l),
+                MARL_TRY(launch_slab_reduce(w.part_w, (int64_t)co * d.K[l], w.blocks, c.gp(4 * l),
                                             c.w.ldp[4 * l], co, d.K[l], w.part_b, grads[4 * l + 1], st));
             } else {
                 MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
@@ -1429,15 +1427,19 @@ int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_
 int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
                          const void* img, const int64_t* pos0, const float* h0, const float* c0,
                          const float* hc0, const float* cc0, const float* noise,
-                         const int64_t* forced_actions, float* step_preds, float* step_logp,
+                         const int64_t* forced_actions, uint64_t rng_seed, uint64_t rng_offset,
+                         const void* counters, float* step_preds, float* step_logp,
                          float* step_values, int64_t* step_pos, int64_t* step_actions, int train,
                          void* stream) {
     Ctx c;
     MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, train, stream, c));
-    if (!img || !pos0 || !h0 || !c0 || !hc0 || !cc0 || (!noise && !forced_actions) || !step_preds ||
-        !step_logp || !step_values) {
+    if (!img || !pos0 || !h0 || !c0 || !hc0 || !cc0 || !step_preds || !step_logp || !step_values) {
         set_error("episode_forward: null argument");
         return MARL_EINVAL;
+    }
+    if (c.d.ns >= 65536) {
+        set_error("episode_forward: more than 65535 steps");
+        return MARL_ELIMIT;
     }
     const Dims& d = c.d;
     MARL_TRY(launch_i64_to_i32(pos0, c.POSs(0), d.R * 2, c.st));
@@ -1470,6 +1472,10 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         SampleArgs a;
         fill_sample_args(c, cfg, t, a);
         a.noise = noise ? noise + (size_t)t * d.R * d.nA : nullptr;
+        a.rng_on = !noise && !forced_actions;  // perf mode: Exp(1) drawn inside the kernel
+        a.rng_seed = rng_seed ^ 0x9E3779B97F4A7C15ull;  // a key of its own (marl_draw_episode uses rng_seed)
+        a.rng_ctr = (rng_offset << 16) + (uint64_t)t;
+        a.rng_off_dev = counters ? &static_cast<const Counters*>(counters)->rng_offset : nullptr;
         a.forced = forced_actions ? forced_actions + (size_t)t * d.R : nullptr;
         a.step_pos = step_pos ? step_pos + (size_t)t * d.R * 2 : nullptr;
         a.step_actions = step_actions ? step_actions + (size_t)t * d.R : nullptr;
@@ -1509,6 +1515,76 @@ int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episod
     return episode_backward(c, img, cfg->img_u8 != 0, g_preds, g_logp, g_values, grads_host);
 }
 
+int marl_draw_episode(const marl_config* cfg, uint64_t seed, uint64_t offset, const void* counters,
+                      int64_t* pos0, float* h0, float* c0, float* hc0, float* cc0, float* noise,
+                      void* stream) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    if (!pos0 || !h0 || !c0 || !hc0 || !cc0) {
+        set_error("draw_episode: null argument");
+        return MARL_EINVAL;
+    }
+    return launch_draw_episode(seed, offset,
+                               counters ? &static_cast<const Counters*>(counters)->rng_offset : nullptr,
+                               pos0, (int)d.R, d.H, d.W, d.f, h0, c0, d.n_b, hc0, cc0, d.n_a, noise,
+                               noise ? d.NR * d.nA : 0, static_cast<hipStream_t>(stream));
+}
+
+int marl_counters_set(void* counters, uint64_t rng_offset, int64_t step, float lr, float beta1,
+                      float beta2, void* stream) {
+    if (!counters || step < 1) {
+        set_error("counters_set: bad argument");
+        return MARL_EINVAL;
+    }
+    return launch_counters_set(static_cast<Counters*>(counters), rng_offset, step, lr, beta1, beta2, 0,
+                               static_cast<hipStream_t>(stream));
+}
+
+int marl_counters_tick(void* counters, float lr, float beta1, float beta2, void* stream) {
+    if (!counters) {
+        set_error("counters_tick: null block");
+        return MARL_EINVAL;
+    }
+    return launch_counters_set(static_cast<Counters*>(counters), 0, 0, lr, beta1, beta2, 1,
+                               static_cast<hipStream_t>(stream));
+}
+
+// ---- hipGraph capture / replay -------------------------------------------------------------
+int marl_graph_begin(void* stream) {
+    if (!stream) {
+        set_error("graph_begin: the NULL stream cannot be captured");
+        return MARL_EINVAL;
+    }
+    MARL_HIP_CHECK(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+    return MARL_OK;
+}
+
+int marl_graph_end(void* stream, void** graph_exec_out) {
+    if (!stream || !graph_exec_out) return MARL_EINVAL;
+    hipGraph_t graph = nullptr;
+    MARL_HIP_CHECK(hipStreamEndCapture(static_cast<hipStream_t>(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return MARL_EHIP;
+    }
+    *graph_exec_out = exec;
+    return MARL_OK;
+}
+
+int marl_graph_launch(void* graph_exec, void* stream) {
+    if (!graph_exec) return MARL_EINVAL;
+    MARL_HIP_CHECK(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+    return MARL_OK;
+}
+
+int marl_graph_destroy(void* graph_exec) {
+    if (graph_exec) MARL_HIP_CHECK(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+    return MARL_OK;
+}
+
 int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float* step_preds,
                           const float* step_logp, const float* step_values, const int64_t* y,
                           float gamma, float* g_preds, float* g_logp, float* g_values,
@@ -1546,7 +1622,7 @@ int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float*
 
 int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                   void* stream) {
+                   const void* counters, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) {
         set_error("adam: bad argument");
         return MARL_EINVAL;
@@ -1555,15 +1631,15 @@ int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, (float)((double)lr / bc1),
                        (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale,
-                       static_cast<hipStream_t>(stream));
+                       static_cast<hipStream_t>(stream), static_cast<const Counters*>(counters));
 }
 
 int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
                       const float* obs, const float* msg, const float* norm_pos, const float* h,
                       const float* cc_, const float* hc, const float* cca, float* probs,
                       float* values, float* preds, float* new_msg, float* h_out, float* c_out,
-                      float* hc_out, float* cc_out, const float* noise, int64_t* actions_out,
-                      float* logp_out, void* stream) {
+                      float* hc_out, float* cc_out, const float* noise, uint64_t rng_seed,
+                      uint64_t rng_offset, int64_t* actions_out, float* logp_out, void* stream) {
     Ctx c;
     MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 0, stream, c));
     if (!obs || !msg || !norm_pos || !h || !cc_ || !hc || !cca || !probs || !values || !preds ||
@@ -1580,8 +1656,11 @@ int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* epis
     SampleArgs a;
     fill_sample_args(c, cfg, 0, a);
     a.probs = probs;
-    if (noise && actions_out && logp_out) {  // also sample (positions of the scratch slot are unused)
+    if (actions_out && logp_out) {  // also sample (positions of the scratch slot are unused)
         a.noise = noise;
+        a.rng_on = !noise;
+        a.rng_seed = rng_seed ^ 0x9E3779B97F4A7C15ull;
+        a.rng_ctr = rng_offset << 16;
         a.step_actions = actions_out;
         a.step_logp = logp_out;
     } else {
@@ -1661,7 +1740,7 @@ int marl_normalize_positions(const int64_t* pos, float* out, int rows, int h, in
 }
 
 int marl_profile_begin(int kernel_class, int max_launches) {
-    if (kernel_class < 0 || kernel_class > 2 || max_launches < 1) return MARL_EINVAL;
+    if (kernel_class < 0 || kernel_class >= kProfClasses || max_launches < 1) return MARL_EINVAL;
     return profile_begin(kernel_class, max_launches);
 }
 int marl_profile_end(double* total_ms, int* launches) { return profile_end(total_ms, launches); }
@@ -1681,6 +1760,69 @@ int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int
                  int64_t rows, float* scratch, size_t scratch_bytes, void* stream) {
     return launch_gemm_tn(a, lda, b, ldb, c, ldc, ni, nj, rows, scratch, scratch_bytes,
                           static_cast<hipStream_t>(stream));
+}
+
+static CnnWgradArgs wgrad_api_args(int64_t rows, int nb, int c_img, int h, int w, int cin, int cout,
+                                   int hin, int groups, int first) {
+    CnnWgradArgs g{};
+    g.rows = rows;
+    g.first = first;
+    g.nb = nb;
+    g.c_img = c_img;
+    g.H = h;
+    g.W = w;
+    g.cin = cin;
+    g.cout = cout;
+    g.hin = hin;
+    g.hout = (hin - 1) / 2 + 1;
+    g.P = g.hout * g.hout;
+    g.G = groups > 0 ? groups : 1;
+    g.K = 9 * cin;
+    return g;
+}
+
+size_t marl_cnn_wgrad_scratch(int64_t rows, int cin, int cout, int hin, int groups, int first) {
+    const CnnWgradArgs g = wgrad_api_args(rows, 1, cin, hin + 1, hin + 1, cin, cout, hin, groups, first);
+    return (size_t)cnn_wgrad_blocks(g) * ((size_t)cout * 9 * cin + cout) * sizeof(float);
+}
+
+int marl_cnn_wgrad(const float* dz, const void* img, int img_u8, const int32_t* pos,
+                   const float* zin, const float* gst, const float* gamma, const float* beta,
+                   int64_t rows, int nb, int c_img, int h, int w, int cin, int cout, int hin,
+                   int groups, float* dw, float* db, float* scratch, size_t scratch_bytes,
+                   void* stream) {
+    const int first = zin == nullptr;
+    if (!dz || !dw || !db || !scratch || rows < 1 || cin < 1 || cout < 1 || hin < 1 ||
+        (first ? (!img || !pos || nb < 1) : (!gst || !gamma || !beta))) {
+        set_error("cnn_wgrad: bad argument");
+        return MARL_EINVAL;
+    }
+    CnnWgradArgs g = wgrad_api_args(rows, nb, c_img, h, w, cin, cout, hin, groups, first);
+    if (!cnn_wgrad_supported(g)) {
+        set_error("cnn_wgrad: shape outside the kernel's range (cin %d cout %d hin %d)", cin, cout, hin);
+        return MARL_ELIMIT;
+    }
+    if (scratch_bytes < marl_cnn_wgrad_scratch(rows, cin, cout, hin, groups, first)) {
+        set_error("cnn_wgrad: scratch too small");
+        return MARL_ESIZE;
+    }
+    g.dz = dz;
+    g.img = img;
+    g.img_u8 = img_u8;
+    g.pos = pos;
+    g.zin = zin;
+    g.gst = gst;
+    g.gamma = gamma;
+    g.beta = beta;
+    g.part_w = scratch;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MARL_TRY(launch_cnn_wgrad(g, st));
+    return launch_slab_reduce(g.part_w, (int64_t)cout * g.K, g.blocks, dw, g.K, cout, g.K, g.part_b, db, st);
+}
+
+int marl_tune(const char* key, int value) {
+    if (!key) return MARL_EINVAL;
+    return tune_set(key, value);
 }
 
 int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,

@@ -573,8 +573,6 @@ void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb,
     p.nseg = 2;
 }
 
-static void prof_before(int cls, hipStream_t st);
-static void prof_after(int cls, hipStream_t st);
 
 template <int BM, int BN, int WM, int WN, bool LSTM, int GROUPS>
 static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t st) {
@@ -684,16 +682,17 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // optional per-launch timing of one kernel class with HIP events recorded on the launch
 // stream (bench.py's roofline figure).  class 0 = fused LSTM GEMM, 1 = plain NT GEMM,
-// 2 = TN GEMM.  Off by default: no events are created or recorded.
+// 2 = TN GEMM, 3 = fused CNN forward, 4 = row-panel MLP kernels, 5 = CNN backward (layer
+// backward + weight gradients).  Off by default: no events are created or recorded.
 // ---------------------------------------------------------------------------
 static int g_prof_class = -1;
 static int g_prof_cap = 0, g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;  // [2 * cap]
 
-static void prof_before(int cls, hipStream_t st) {
+void prof_before(int cls, hipStream_t st) {
     if (cls == g_prof_class && g_prof_n < g_prof_cap) (void)hipEventRecord(g_prof_ev[2 * g_prof_n], st);
 }
-static void prof_after(int cls, hipStream_t st) {
+void prof_after(int cls, hipStream_t st) {
     if (cls == g_prof_class && g_prof_n < g_prof_cap) {
         (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], st);
         ++g_prof_n;

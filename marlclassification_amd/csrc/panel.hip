@@ -378,6 +378,7 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
         raised = true;
     }
     const unsigned pblocks = (unsigned)cdiv(mmax, kPanelRows);
+    prof_before(4, st);
     if (b.has_sample && b.count == 1) {
         b.panel_blocks = (int)pblocks;
         const unsigned sblocks = (unsigned)cdiv(b.sample.R, waves);
@@ -387,6 +388,7 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
         hipLaunchKernelGGL(panel_fwd_kernel<false>, dim3(pblocks, (unsigned)b.count), dim3(64 * waves),
                            lds, st, b);
     }
+    prof_after(4, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -635,6 +637,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
         raised = true;
     }
     const unsigned pblocks = (unsigned)cdiv(p.m, kPanelRows);
+    prof_before(4, st);
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
         const unsigned cblocks = (unsigned)cdiv(p.cell_rows * p.cell.n, 64 * waves);
@@ -642,6 +645,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     } else {
         hipLaunchKernelGGL(panel_bwd_kernel<false>, dim3(pblocks), dim3(64 * waves), lds, st, p);
     }
+    prof_after(4, st);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

@@ -5,6 +5,10 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "sample.h"
 
@@ -18,6 +22,52 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+// ---- tuning knobs ----------------------------------------------------------------------
+namespace {
+struct Knob {
+    char key[32];
+    int value;
+    bool set;
+};
+Knob g_knobs[32];
+int g_nknobs = 0;
+Knob* knob(const char* key, bool create) {
+    for (int i = 0; i < g_nknobs; ++i)
+        if (!strcmp(g_knobs[i].key, key)) return &g_knobs[i];
+    if (!create || g_nknobs >= 32 || strlen(key) >= sizeof(g_knobs[0].key)) return nullptr;
+    Knob* k = &g_knobs[g_nknobs++];
+    strcpy(k->key, key);
+    k->value = 0;
+    k->set = false;
+    return k;
+}
+}  // namespace
+
+int tune_set(const char* key, int value) {
+    Knob* k = knob(key, true);
+    if (!k) return MARL_EINVAL;
+    k->value = value;
+    k->set = true;
+    return MARL_OK;
+}
+
+int tune_get(const char* key, int dflt) {
+    Knob* k = knob(key, true);
+    if (k && k->set) return k->value;
+    // first use: take the environment's value (MARL_<KEY>), remember the outcome
+    char env[48] = "MARL_";
+    size_t n = strlen(env);
+    for (const char* c = key; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+    env[n] = 0;
+    const char* e = getenv(env);
+    const int v = e ? atoi(e) : dflt;
+    if (k && e) {
+        k->value = v;
+        k->set = true;
+    }
+    return v;
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -923,6 +973,87 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// Perf-mode episode draws: one launch replaces the reference's seven draw calls
+// (environment.py:33-43: randint per dimension; models.py:148-159: four randn) and, when asked,
+// the per-step exponential_() of th.multinomial.  Element e of stream s uses Philox counter
+// (offset, s, e / 4): independent of the grid, reproducible for a (seed, offset) pair.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void draw_episode_kernel(
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev,
+    int64_t* __restrict__ pos0, int R, int H, int W, int f,
+    float* __restrict__ h0, float* __restrict__ c0, int64_t nb_el, float* __restrict__ hc0,
+    float* __restrict__ cc0, int64_t na_el, float* __restrict__ noise, int64_t n_noise,
+    int64_t q_pos, int64_t q_b, int64_t q_a, int64_t q_n) {
+    // quads (4 values each) are laid out stream after stream: pos | h0 | c0 | hc0 | cc0 | noise
+    if (offset_dev) offset += *offset_dev;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t rel = q;
+    if (rel < q_pos) {  // two rows (4 coordinates) per quad
+        const Philox4 u = philox4x32_10(seed, offset, (uint32_t)rel, 0u);
+        const uint32_t uv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t e = rel * 4 + i;
+            if (e < (int64_t)R * 2) {
+                const uint32_t span = (uint32_t)(((e & 1) ? W : H) - f);
+                pos0[e] = (int64_t)(((uint64_t)uv[i] * span) >> 32);  // [0, span)
+            }
+        }
+        return;
+    }
+    rel -= q_pos;
+    float* dst = nullptr;
+    int64_t n = 0;
+    uint32_t stream = 1;
+    bool normal = true;
+    if (rel < q_b) {
+        dst = h0, n = nb_el, stream = 1;
+    } else if ((rel -= q_b) < q_b) {
+        dst = c0, n = nb_el, stream = 2;
+    } else if ((rel -= q_b) < q_a) {
+        dst = hc0, n = na_el, stream = 3;
+    } else if ((rel -= q_a) < q_a) {
+        dst = cc0, n = na_el, stream = 4;
+    } else if ((rel -= q_a) < q_n) {
+        dst = noise, n = n_noise, stream = 5, normal = false;
+    } else {
+        return;
+    }
+    const Philox4 u = philox4x32_10(seed, offset, (uint32_t)rel, stream | ((uint32_t)(rel >> 32) << 8));
+    float v[4];
+    if (normal) {  // Box-Muller on two pairs
+        const float r0 = sqrtf(-2.0f * logf(philox_u01(u.x))), r1 = sqrtf(-2.0f * logf(philox_u01(u.z)));
+        const float a0 = 6.283185307179586f * philox_u01(u.y), a1 = 6.283185307179586f * philox_u01(u.w);
+        v[0] = r0 * cosf(a0);
+        v[1] = r0 * sinf(a0);
+        v[2] = r1 * cosf(a1);
+        v[3] = r1 * sinf(a1);
+    } else {  // Exp(1)
+        v[0] = -logf(philox_u01(u.x));
+        v[1] = -logf(philox_u01(u.y));
+        v[2] = -logf(philox_u01(u.z));
+        v[3] = -logf(philox_u01(u.w));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (rel * 4 + i < n) dst[rel * 4 + i] = v[i];
+}
+
+int launch_draw_episode(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t* pos0,
+                        int R, int H, int W, int f, float* h0, float* c0, int n_b, float* hc0,
+                        float* cc0, int n_a, float* noise, int64_t n_noise, hipStream_t st) {
+    const int64_t nb_el = (int64_t)R * n_b, na_el = (int64_t)R * n_a;
+    const int64_t q_pos = cdiv((int64_t)R * 2, 4), q_b = cdiv(nb_el, 4), q_a = cdiv(na_el, 4),
+                  q_n = noise ? cdiv(n_noise, 4) : 0;
+    const int64_t total = q_pos + 2 * q_b + 2 * q_a + q_n;
+    hipLaunchKernelGGL(draw_episode_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, seed,
+                       offset, offset_dev, pos0, R, H, W, f, h0, c0, nb_el, hc0, cc0, na_el, noise, n_noise, q_pos,
+                       q_b, q_a, q_n);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
 // permuted copies (weight packing / gradient unpacking)
 // ---------------------------------------------------------------------------
 __global__ void permute_kernel(const PermBatch B) {
@@ -961,7 +1092,11 @@ int launch_permute(const PermBatch& b, hipStream_t st) {
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, int64_t n,
                             float step_size, float inv_sqrt_bc2, float beta1, float beta2,
-                            float eps, float grad_scale) {
+                            float eps, float grad_scale, const Counters* __restrict__ cnt) {
+    if (cnt) {  // graph replay: the step-dependent scalars live on the device
+        step_size = cnt->lr_over_bc1;
+        inv_sqrt_bc2 = cnt->inv_sqrt_bc2;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float gr = g[i] * grad_scale;
@@ -976,12 +1111,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_over_bc1,
                 float inv_sqrt_bc2, float beta1, float beta2, float eps, float grad_scale,
-                hipStream_t st) {
+                hipStream_t st, const Counters* cnt) {
     if (n <= 0) return MARL_OK;
     int64_t gx = cdiv(n, 256);
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, st, p, g, m, v, n,
-                       lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, grad_scale);
+                       lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, grad_scale, cnt);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// counter block: set (tick = 0) or advance by one iteration (tick = 1); one thread
+__global__ void counters_kernel(Counters* c, uint64_t rng_offset, int64_t step, float lr, float beta1,
+                                float beta2, int tick) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t off = rng_offset, st = (uint64_t)step;
+    if (tick) {
+        off = c->rng_offset + 1;
+        st = c->step + 1;
+    }
+    c->rng_offset = off;
+    c->step = st;
+    const double bc1 = 1.0 - pow((double)beta1, (double)st);
+    const double bc2 = 1.0 - pow((double)beta2, (double)st);
+    c->lr_over_bc1 = (float)((double)lr / bc1);
+    c->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+int launch_counters_set(Counters* c, uint64_t rng_offset, int64_t step, float lr, float beta1,
+                        float beta2, int tick, hipStream_t st) {
+    hipLaunchKernelGGL(counters_kernel, dim3(1), dim3(64), 0, st, c, rng_offset, step, lr, beta1, beta2, tick);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

@@ -11,6 +11,28 @@ namespace marl {
 
 __device__ __forceinline__ float sample_silu(float y) { return y / (1.0f + expf(-y)); }
 
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): a
+// counter-based generator - four 32-bit words per (key, counter), no state to carry between
+// kernels, so every row draws its own stream wherever and whenever it runs.
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t key, uint64_t ctr_hi, uint32_t c0, uint32_t c1) {
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    Philox4 c{c0, c1, (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = Philox4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// uniform in (0, 1): never 0 (log) and never 1
+__device__ __forceinline__ float philox_u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
 // p[j] += sum over this lane's columns base + lane + 64u of a[u] * w1[j][col]; the output
 // layer's rows are read four actions at a time so that all loads of a group are in flight
 __device__ __forceinline__ void sample_logits_chunk(const SampleArgs& A, const float (&a)[8], int base,
@@ -91,6 +113,28 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
                 }
             }
         }
+    if (!A.noise && A.rng_on) {
+        // th.multinomial(p, 1) == argmax_j p_j / q_j with q ~ Exp(1) (core/agent.py:53-55); here
+        // q_j = -log(u_j) from this row's own Philox stream (wave-uniform, every lane agrees)
+#pragma unroll
+        for (int j0 = 0; j0 < MARL_MAX_ACTIONS; j0 += 4) {
+            if (j0 < A.nA) {
+                const uint64_t ctr = A.rng_ctr + (A.rng_off_dev ? (*A.rng_off_dev << 16) : 0ull);
+                const Philox4 u = philox4x32_10(A.rng_seed, ctr, (uint32_t)r, (uint32_t)(j0 >> 2));
+                const uint32_t uv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (j0 + jj < A.nA) {
+                        const float sc = p[j0 + jj] / -__logf(philox_u01(uv[jj]));
+                        if (sc > best) {
+                            best = sc;
+                            act = j0 + jj;
+                        }
+                    }
+                }
+            }
+        }
+    }
     if (!A.step_logp) {  // standalone step API: probabilities only
         if (lane == 0)
 #pragma unroll
@@ -98,7 +142,10 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
                 if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
         return;
     }
-    if (A.forced) act = (int)A.forced[r];
+    if (A.forced) {  // teacher forcing; out-of-range indices are clamped like transition_kernel does
+        const int fa = (int)A.forced[r];
+        act = fa < 0 ? 0 : (fa >= A.nA ? A.nA - 1 : fa);
+    }
 #pragma unroll
     for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
         if (j == act) pa = p[j];

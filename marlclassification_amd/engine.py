@@ -121,6 +121,9 @@ class ModelSpec:
         return len(CNN_SPECS[self.ft_extr][1])
 
 
+_U64 = (1 << 64) - 1
+
+
 def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -224,8 +227,11 @@ class HipEngine:
     def episode_forward(
         self, img: th.Tensor, pos0: th.Tensor, h0: th.Tensor, c0: th.Tensor, hc0: th.Tensor,
         cc0: th.Tensor, noise: Optional[th.Tensor], forced_actions: Optional[th.Tensor] = None,
-        train: bool = True,
+        train: bool = True, rng: Optional[Tuple[int, int]] = None,
+        out: Optional[EpisodeTensors] = None, counters: Optional[th.Tensor] = None,
     ) -> EpisodeTensors:
+        """``noise`` = injected Exp(1) draws [Ns,Na,Nb,nA] (parity mode); ``noise=None`` with
+        ``rng=(seed, offset)`` draws them inside the sampling kernel (perf mode)."""
         cfg = self.cfg
         assert cfg is not None
         na, nb, ns = cfg.nb_agents, cfg.batch, cfg.nb_steps
@@ -238,24 +244,34 @@ class HipEngine:
             noise = _need(noise, th.float32, "noise")
         if forced_actions is not None:
             forced_actions = _need(forced_actions, th.int64, "forced_actions")
-        out = EpisodeTensors(
-            th.empty(ns, na, nb, cfg.nb_class, device=dev),
-            th.empty(ns, na, nb, device=dev),
-            th.empty(ns, na, nb, device=dev),
-            th.empty(ns, na, nb, 2, dtype=th.int64, device=dev),
-            th.empty(ns, na, nb, dtype=th.int64, device=dev),
-        )
+        if noise is None and forced_actions is None and rng is None:
+            raise ValueError("episode_forward needs noise, forced_actions or rng=(seed, offset)")
+        seed, offset = rng if rng is not None else (0, 0)
+        if out is None:  # (graph capture passes persistent output tensors: nothing may allocate)
+            out = self.new_outputs()
         check(self.lib.marl_episode_forward(
             C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(train).data_ptr(),
             img.data_ptr(), pos0.data_ptr(), h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(),
-            cc0.data_ptr(), _ptr(noise), _ptr(forced_actions),
-            out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
+            cc0.data_ptr(), _ptr(noise), _ptr(forced_actions), seed & _U64, offset & _U64,
+            _ptr(counters), out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
             out.step_pos.data_ptr(), out.step_actions.data_ptr(), int(train), _stream(dev)))
         if train:
             self.fwd_generation += 1
             self._fwd_img = img
             self._fwd_key = self._cfg_key
         return out
+
+    def new_outputs(self) -> EpisodeTensors:
+        cfg = self.cfg
+        assert cfg is not None
+        na, nb, ns, dev = cfg.nb_agents, cfg.batch, cfg.nb_steps, self.device
+        return EpisodeTensors(
+            th.empty(ns, na, nb, cfg.nb_class, device=dev),
+            th.empty(ns, na, nb, device=dev),
+            th.empty(ns, na, nb, device=dev),
+            th.empty(ns, na, nb, 2, dtype=th.int64, device=dev),
+            th.empty(ns, na, nb, dtype=th.int64, device=dev),
+        )
 
     def episode_backward(
         self, g_preds: Optional[th.Tensor], g_logp: Optional[th.Tensor],
@@ -311,21 +327,24 @@ class HipEngine:
     def adam(
         self, params: th.Tensor, grads: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor,
         step: int, lr: float, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-        grad_scale: float = 1.0,
+        grad_scale: float = 1.0, counters: Optional[th.Tensor] = None,
     ) -> None:
         for t in (params, grads, exp_avg, exp_avg_sq):
             if not t.is_cuda or t.dtype != th.float32 or not t.is_contiguous():
                 raise RuntimeError("adam buffers must be contiguous fp32 GPU tensors")
         check(self.lib.marl_adam_step(
             params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
-            params.numel(), step, lr, betas[0], betas[1], eps, grad_scale, _stream(self.device)))
+            params.numel(), step, lr, betas[0], betas[1], eps, grad_scale, _ptr(counters),
+            _stream(self.device)))
 
     def step_forward(
         self, obs: th.Tensor, msg: th.Tensor, norm_pos: th.Tensor, h: th.Tensor, c: th.Tensor,
         hc: th.Tensor, cc: th.Tensor, noise: Optional[th.Tensor] = None,
+        rng: Optional[Tuple[int, int]] = None,
     ) -> Tuple[th.Tensor, ...]:
         """marl_step_forward: (probs, values, preds, new_msg, h, c, hc, cc) in [Na,Nb,..];
-        with ``noise`` ([Na,Nb,nA] ~ Exp(1)) also (actions int64, log-probs)."""
+        with ``noise`` ([Na,Nb,nA] ~ Exp(1), parity mode) or ``rng=(seed, offset)`` (in-kernel
+        draws) also (actions int64, log-probs)."""
         cfg = self.cfg
         assert cfg is not None
         na, nb = cfg.nb_agents, cfg.batch
@@ -341,16 +360,64 @@ class HipEngine:
         )
         extra: Tuple[th.Tensor, ...] = ()
         nz = act = lp = None
-        if noise is not None:
-            nz = _need(noise, th.float32, "noise")
+        if noise is not None or rng is not None:
+            nz = None if noise is None else _need(noise, th.float32, "noise")
             act = th.empty(na, nb, dtype=th.int64, device=dev)
             lp = th.empty(na, nb, device=dev)
             extra = (act, lp)
+        seed, offset = rng if rng is not None else (0, 0)
         check(self.lib.marl_step_forward(
             C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(False).data_ptr(),
-            *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _ptr(nz), _ptr(act),
-            _ptr(lp), _stream(dev)))
+            *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _ptr(nz), seed & _U64,
+            offset & _U64, _ptr(act), _ptr(lp), _stream(dev)))
         return outs + extra
+
+    def draw_episode(self, seed: int, offset: int, with_noise: bool = False,
+                     into: Optional[Tuple[th.Tensor, ...]] = None,
+                     counters: Optional[th.Tensor] = None):
+        """marl_draw_episode: the reference's reset draws (positions, h, c, h^, c^; optionally the
+        per-step Exp(1) noise) from the library's counter-based generator in ONE launch.
+        Returns (pos0, h0, c0, hc0, cc0, noise-or-None); ``into`` = persistent tensors to fill."""
+        cfg = self.cfg
+        assert cfg is not None
+        na, nb, ns, dev = cfg.nb_agents, cfg.batch, cfg.nb_steps, self.device
+        if into is None:
+            into = (
+                th.empty(na, nb, 2, dtype=th.int64, device=dev),
+                th.empty(na, nb, cfg.n_b, device=dev), th.empty(na, nb, cfg.n_b, device=dev),
+                th.empty(na, nb, cfg.n_a, device=dev), th.empty(na, nb, cfg.n_a, device=dev),
+                th.empty(ns, na, nb, cfg.nb_action, device=dev) if with_noise else None,
+            )
+        pos0, h0, c0, hc0, cc0, noise = into
+        check(self.lib.marl_draw_episode(
+            C.byref(cfg), seed & _U64, offset & _U64, _ptr(counters), pos0.data_ptr(),
+            h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(), cc0.data_ptr(), _ptr(noise), _stream(dev)))
+        return into
+
+    # -- device-side iteration counters + hipGraph capture (marl_counters_*, marl_graph_*) ------
+    def new_counters(self) -> th.Tensor:
+        return th.zeros(_lib.MARL_COUNTERS_BYTES // 8, dtype=th.int64, device=self.device)
+
+    def counters_set(self, counters: th.Tensor, rng_offset: int, step: int, lr: float,
+                     betas: Tuple[float, float] = (0.9, 0.999)) -> None:
+        check(self.lib.marl_counters_set(counters.data_ptr(), rng_offset & _U64, step, lr, betas[0],
+                                         betas[1], _stream(self.device)))
+
+    def counters_tick(self, counters: th.Tensor, lr: float,
+                      betas: Tuple[float, float] = (0.9, 0.999)) -> None:
+        check(self.lib.marl_counters_tick(counters.data_ptr(), lr, betas[0], betas[1],
+                                          _stream(self.device)))
+
+    def graph_begin(self) -> None:
+        check(self.lib.marl_graph_begin(_stream(self.device)))
+
+    def graph_end(self) -> int:
+        handle = C.c_void_p(0)
+        check(self.lib.marl_graph_end(_stream(self.device), C.byref(handle)))
+        return handle.value
+
+    def graph_launch(self, handle: int) -> None:
+        check(self.lib.marl_graph_launch(handle, _stream(self.device)))
 
     def debug_buffer(self, name: str, t: int, train: bool = True) -> th.Tensor:
         """View [R, ld] of a named per-step activation inside the episode workspace (tests)."""

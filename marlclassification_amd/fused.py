@@ -28,7 +28,8 @@ class EpisodeDraws:
     c0: th.Tensor
     hc0: th.Tensor
     cc0: th.Tensor
-    noise: th.Tensor
+    noise: Optional[th.Tensor]  # None: the sampling kernel draws its own Exp(1) variates (`rng`)
+    rng: Optional[Tuple[int, int]] = None  # (seed, offset) of the library's counter-based generator
 
 
 def draw_episode(spec: ModelSpec, na: int, nb: int, ns: int, sizes, device,
@@ -47,6 +48,13 @@ def draw_episode(spec: ModelSpec, na: int, nb: int, ns: int, sizes, device,
         1.0, generator=generator
     )
     return EpisodeDraws(pos0, h0, c0, hc0, cc0, noise)
+
+
+def draw_episode_device(engine: HipEngine, seed: int, offset: int) -> EpisodeDraws:
+    """Perf mode: every draw of the episode comes from the library (one launch for positions
+    and initial states; the per-step Exp(1) noise is drawn inside the sampling kernel)."""
+    pos0, h0, c0, hc0, cc0, _ = engine.draw_episode(seed, offset)
+    return EpisodeDraws(pos0, h0, c0, hc0, cc0, None, (seed, offset))
 
 
 class FlatParams:
@@ -97,7 +105,11 @@ class FusedA2C:
     """rollout + loss + backward + Adam on one GPU; ``allreduce`` hooks in data parallelism."""
 
     def __init__(self, engine: HipEngine, flat: FlatParams, lr: float, gamma: float,
-                 allreduce: Optional[Callable[[th.Tensor], float]] = None) -> None:
+                 allreduce: Optional[Callable[[th.Tensor], float]] = None,
+                 use_graph: bool = False) -> None:
+        if use_graph and allreduce is not None:
+            raise ValueError("hipGraph replay covers the single-GPU iteration (no collective inside)")
+        self._graph = None  # (key, exec handle, stream, persistent tensors)
         self.engine = engine
         self.flat = flat
         self.lr = lr
@@ -117,7 +129,58 @@ class FusedA2C:
         if not self._packed:
             self.pack()
         return self.engine.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0,
-                                           draws.cc0, draws.noise, forced_actions, train)
+                                           draws.cc0, draws.noise, forced_actions, train,
+                                           rng=draws.rng)
+
+    def iteration_graph(self, img: th.Tensor, y: th.Tensor, seed: int,
+                        offset: int) -> Tuple[EpisodeTensors, th.Tensor]:
+        """The same iteration as ONE hipGraph replay (launch-bound shapes: hundreds of small
+        kernels per iteration).  The first call runs one eager iteration (one-off set-up inside
+        the library), then captures draw -> rollout -> loss -> backward -> Adam -> re-pack ->
+        counter tick on a side stream; later calls replay it.  What changes between iterations
+        lives on the device (generator offset, Adam step: the counter block), ``img`` / ``y`` are
+        read from the tensors of the capturing call (same storage every call, or re-capture).
+        Outputs are persistent tensors, overwritten by every replay."""
+        eng = self.engine
+        key = (img.data_ptr(), y.data_ptr(), eng._cfg_key, seed)
+        if self._graph is None or self._graph[0] != key:
+            if self._graph is not None:
+                eng.lib.marl_graph_destroy(self._graph[1])
+            # this call runs eagerly (one-off set-up inside the library happens here) ...
+            eager = self.iteration(img, y, draw_episode_device(eng, seed, offset))
+            offset += 1  # ... and the graph captured below starts at the NEXT iteration
+            stream = th.cuda.Stream(device=eng.device)
+            out = eng.new_outputs()
+            draws = eng.draw_episode(seed, 0)  # persistent draw tensors
+            cnt = eng.new_counters()
+            gviews = self._gviews
+            stream.wait_stream(th.cuda.current_stream(eng.device))
+            with th.cuda.stream(stream):
+                eng.counters_set(cnt, offset, self.flat.step + 1, self.lr)
+                th.cuda.synchronize(eng.device)
+                eng.graph_begin()
+                try:
+                    eng.draw_episode(seed, 0, into=draws, counters=cnt)
+                    eng.episode_forward(img, draws[0], draws[1], draws[2], draws[3], draws[4], None,
+                                        None, True, rng=(seed, 0), out=out, counters=cnt)
+                    gp, gl, gv, scalars, _ = eng.a2c_loss(out, y, self.gamma, 0, self._loss_bufs)
+                    eng.episode_backward(gp, gl, gv, gviews)
+                    eng.adam(self.flat.params, self.flat.grads, self.flat.exp_avg,
+                             self.flat.exp_avg_sq, 1, self.lr, counters=cnt)
+                    eng.pack(self._pviews)
+                    eng.counters_tick(cnt, self.lr)
+                finally:
+                    handle = eng.graph_end()
+            self._graph = (key, handle, stream, (out, draws, cnt, scalars))
+            return eager
+        _, handle, stream, (out, _draws, _cnt, scalars) = self._graph
+        stream.wait_stream(th.cuda.current_stream(eng.device))
+        with th.cuda.stream(stream):
+            eng.graph_launch(handle)
+        th.cuda.current_stream(eng.device).wait_stream(stream)
+        self.flat.step += 1
+        eng.fwd_generation += 1
+        return out, scalars
 
     def iteration(self, img: th.Tensor, y: th.Tensor, draws: EpisodeDraws) -> Tuple[EpisodeTensors, th.Tensor]:
         """Returns the episode outputs and the device tensor {loss, path, error, critic}."""

@@ -25,6 +25,16 @@ class ConfusionMeter:
             return th.zeros(self.__nb_class, self.__nb_class, dtype=th.long)
         return th.stack(tuple(self.__window)).sum(0).view(self.__nb_class, self.__nb_class)
 
+    def all_reduce(self, group=None) -> None:
+        """Data-parallel evaluation: every rank saw its shard; sum the confusion matrices so that
+        precision / recall describe the WHOLE evaluation set on every rank."""
+        from .parallel import allreduce_confusion
+
+        cm = self.conf_mat().flatten().contiguous()
+        allreduce_confusion(cm, group)
+        self.__window.clear()
+        self.__window.append(cm)
+
     def precision(self) -> th.Tensor:
         cm = self.conf_mat().to(th.float)
         return cm.diagonal() / (cm.sum(dim=0) + 1e-8)

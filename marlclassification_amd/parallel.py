@@ -33,6 +33,19 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
+def _all_reduce_sum(t: th.Tensor, group=None) -> th.Tensor:
+    """Sum-all-reduce in place.  GPU tensors go straight to RCCL ("nccl" backend); under a
+    "gloo" group (CPU-only rendezvous, the 2-rank tests that share one GPU) they bounce through
+    the host."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class GradAllReduce:
     """Sum-all-reduce of the flat gradient buffer; returns the scale (1 / world) that the
     Adam kernel applies while it reads the gradient (no separate divide pass)."""
@@ -42,12 +55,26 @@ class GradAllReduce:
         self.group = group
 
     def __call__(self, flat_grads: th.Tensor) -> float:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        _all_reduce_sum(flat_grads, self.group)
         return 1.0 / self.world
 
 
 def allreduce_adv_stats(stats: th.Tensor, group=None) -> th.Tensor:
     """(n, sum, sum of squares) of the advantages summed over ranks: the exchange step of
     the exact global ``standardize``."""
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    return stats
+    return _all_reduce_sum(stats, group)
+
+
+def broadcast_parameters(flat_params: th.Tensor, src: int = 0, group=None) -> None:
+    """Identical initial weights on every rank: one broadcast of the flat parameter buffer."""
+    if flat_params.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat_params.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat_params.copy_(host)
+    else:
+        dist.broadcast(flat_params, src=src, group=group)
+
+
+def allreduce_confusion(conf_mat: th.Tensor, group=None) -> th.Tensor:
+    """Evaluation metrics over the WHOLE evaluation set: sum the per-rank confusion matrices."""
+    return _all_reduce_sum(conf_mat, group)

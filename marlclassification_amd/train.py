@@ -15,18 +15,43 @@ from torch.utils.data import DataLoader, Subset
 
 from .config import MainConfig, ModelConfig, TrainConfig
 from .core import EpisodeSampler
-from .data import ImageFolderU8, SyntheticImages
+from .data import DevicePrefetcher, ImageFolderU8, SyntheticImages
 from .parallel import GradAllReduce, shard_bounds
 from .training import Trainer
 
 
+# where each image-folder dataset lives under the resources directory (reference
+# data/datasets.py:25-79,217-235: MnistDataset / Resisc45Dataset / AidDataset / SkinCancerDataset)
+_DATASET_SUBDIR = {
+    "mnist": ("downloaded", "mnist_png", "all_png"),
+    "resisc45": ("downloaded", "NWPU-RESISC45"),
+    "aid": ("downloaded", "AID"),
+    "skin_cancer": ("downloaded", "skin_cancer"),
+}
+
+
 def _dataset(model_config: ModelConfig, train_config: TrainConfig):
+    """``--res-folder synthetic`` (explicit) = random images of the configured shape; anything else
+    must be the reference's resources directory: the dataset is read from the same sub-folder
+    the reference's dataset class uses, and a missing folder is an error (never silent noise)."""
     root = train_config.resources_dir
-    if root == "synthetic" or not exists(root):
+    if root == "synthetic":
         channels = 1 if model_config.ft_extr_str == "mnist" else 3
         return SyntheticImages(max(4 * train_config.batch_size, 64), channels, train_config.img_size,
                                model_config.nb_class)
-    return ImageFolderU8(root)
+    sub = _DATASET_SUBDIR.get(model_config.ft_extr_str)
+    if sub is None:
+        raise ValueError(f'no image-folder dataset is known for "{model_config.ft_extr_str}" '
+                         f"(supported: {sorted(_DATASET_SUBDIR)}, or --res-folder synthetic)")
+    path = join(root, *sub)
+    if not (exists(path) and isdir(path)):
+        raise NotADirectoryError(f'"{path}" does not exist or is not a directory '
+                                 "(pass the reference's resources folder, or --res-folder synthetic)")
+    dataset = ImageFolderU8(path, img_size=train_config.img_size)
+    if len(dataset) == 0 or len(dataset.class_to_idx) != model_config.nb_class:
+        raise ValueError(f'"{path}": {len(dataset)} images in {len(dataset.class_to_idx)} classes, '
+                         f"--nb-class is {model_config.nb_class}")
+    return dataset
 
 
 class _Sharded:
@@ -45,7 +70,9 @@ class _Sharded:
 
 
 def train_main(main_config: MainConfig, model_config: ModelConfig, train_config: TrainConfig,
-               metric_logger=None) -> Trainer:
+               metric_logger=None, exact_standardize: bool = False) -> Trainer:
+    """``exact_standardize`` (multi-GPU): one extra 3-double all-reduce per iteration makes the
+    advantage standardisation global, so the update equals the single-GPU big-batch update."""
     assert model_config.state_dim == 2, "the HIP path implements 2-D images (state_dim == 2)"
     output_dir = train_config.output_dir
     model_dir = join(output_dir, "models")
@@ -86,15 +113,20 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
         dl = DataLoader(Subset(dataset, part), batch_size=train_config.batch_size, shuffle=True,
                         num_workers=0, drop_last=False, pin_memory=True,
                         generator=th.Generator().manual_seed(1))
-        loaders.append(_Sharded(dl, rank, world) if distributed else dl)
+        dl = _Sharded(dl, rank, world) if distributed else dl
+        loaders.append(DevicePrefetcher(dl, device))  # upload of batch i+1 overlaps step i
 
     sampler = EpisodeSampler(marl_m, env, main_config.step)
     trainer = Trainer(nn_models, marl_m.nb_class, train_config.learning_rate, train_config.gamma,
                       metric_logger=metric_logger if rank == 0 else None,
-                      allreduce=GradAllReduce(world) if distributed else None)
+                      allreduce=GradAllReduce(world) if distributed else None,
+                      exact_standardize_group=(dist.group.WORLD if distributed and exact_standardize
+                                               else None))
     for e in range(train_config.nb_epoch):
         trainer.train_epoch(loaders[0], e, sampler)
         conf = trainer.eval_epoch(loaders[1], e, sampler)
+        if distributed:
+            conf.all_reduce()  # every rank evaluated its shard only
         if rank == 0:
             m: Dict[str, float] = trainer.metrics()
             m["eval_prec"] = conf.precision().mean().item()

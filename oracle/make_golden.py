@@ -15,7 +15,7 @@ data only (inputs + expected outputs); no reference source is stored.
 
 Cases: G1 conftest-size odd dims, G2 MNIST config C1,
 G3 shipped MNIST checkpoint replay (5 actions incl. [0,0]), G4 RESISC45 dims
-tiny batch, G5 unit known-answer vectors.
+tiny batch, G5 unit known-answer vectors, G6 initial weights under fixed seeds.
 """
 
 from __future__ import annotations
@@ -278,9 +278,36 @@ def g5() -> None:
     print(f"g5: unit KATs == reference; wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def g6() -> None:
+    """Initial weights (networks/init.py:6-29 applied by models.py:76): what the
+    reference's constructor leaves in every parameter under a fixed torch seed.  The fixture
+    holds, per parameter, its float64 sum, float64 sum of |w| and its first eight values - enough
+    to pin an init recipe + draw order bit for bit without shipping the tensors."""
+    cases = {
+        "mnist_conftest": (mo.OracleConfig("mnist", 12, 23, 22, 21, 20, 19, 10, 24, 25), 123),
+        "resisc45_readme": (mo.OracleConfig("resisc45", 12, 256, 256, 64, 96, 16, 45, 384, 384), 7),
+        "aid_readme": (mo.OracleConfig("aid", 24, 256, 256, 64, 96, 16, 30, 320, 320), 3),
+    }
+    fx = {}
+    for tag, (cfg, seed) in cases.items():
+        th.manual_seed(seed)
+        model, _, _ = build_reference(cfg, 3)
+        sd = model.state_dict()
+        assert {k: tuple(v.shape) for k, v in sd.items()} == mo.param_shapes(cfg)
+        fx[f"{tag}/seed"] = np.array([seed])
+        fx[f"{tag}/names"] = np.array(list(sd))
+        fx[f"{tag}/sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        fx[f"{tag}/abs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        fx[f"{tag}/head"] = np.stack([
+            np.pad(v.flatten()[:8].numpy(), (0, max(0, 8 - v.numel()))) for v in sd.values()])
+    path = os.path.join(OUT, "g6_init.npz")
+    np.savez_compressed(path, **fx)
+    print(f"g6: reference initial weights under fixed seeds; wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     th.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
         globals()[w]()
