@@ -6,6 +6,8 @@
 // NHWC activations give 16-byte contiguous chunks.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace marl {
@@ -371,6 +373,446 @@ __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Second-generation fused forward for small extractors (every layer's weights fit LDS together).
+// What the first kernel spends its time on is latency, not work: every 16x16 tile re-streams
+// its weights from L2, every layer has three workgroup barriers, GroupNorm walks LDS twice.
+// Here
+//   * 256 persistent workgroups copy ALL conv weights into LDS once, then walk chunks of 8 patches;
+//   * in the layers whose output has few positions a WAVE owns a patch end to end (gather ->
+//     conv tiles -> GroupNorm statistics by cross-lane sums over the accumulator registers ->
+//     normalise + SiLU -> next layer's zero-bordered LDS image): no workgroup barrier at all;
+//   * the last layer (4 positions per patch) runs as 16-row tiles over 4 patches, again with the
+//     statistics taken from the registers; two barriers per chunk in total;
+//   * zero borders around every LDS image make every tap address valid (no masks in the loops).
+// Same math, same summation order inside a tile as cnn_fwd_kernel (k ascending), so the results
+// agree with it to the last bits the parity tests look at.
+// ---------------------------------------------------------------------------
+// all-reduce over aligned blocks of `n` lanes (n = 1, 2, 4, 8, 16) inside a 16-lane row: DPP
+// quad permutes and row mirrors on the VALU, no LDS-crossbar shuffles
+__device__ __forceinline__ float row_block_sum(float v, int n) {
+#define MARL_DPP_XADD(ctrl) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    if (n >= 2) MARL_DPP_XADD(0xB1);   // quad_perm [1,0,3,2]
+    if (n >= 4) MARL_DPP_XADD(0x4E);   // quad_perm [2,3,0,1]
+    if (n >= 8) MARL_DPP_XADD(0x141);  // row_half_mirror: the other quad of the 8-lane block
+    if (n >= 16) MARL_DPP_XADD(0x140); // row_mirror: the other half of the row
+#undef MARL_DPP_XADD
+    return v;
+}
+// all-reduce over the four 16-lane rows of a wave (same position inside the row)
+__device__ __forceinline__ float cross_row_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// The network shape is a TEMPLATE parameter: with run-time layer dimensions the tile loops are
+// full of scalar branches, divisions and kernel-argument reloads and the kernel is bound by
+// instruction issue (measured: 3x slower than this form).  One instantiation per extractor of
+// the reference (networks/vision.py:55-127) at its README window; other shapes use cnn_fwd_kernel.
+template <int F_, int L_, int C0, int C1, int C2, int C3, int G0, int G1, int G2>
+struct Fwd2Net {
+    static constexpr int F = F_, L = L_;
+    static constexpr int ch(int l) { return l == 0 ? C0 : l == 1 ? C1 : l == 2 ? C2 : C3; }
+    static constexpr int grp(int l) { return l == 0 ? G0 : l == 1 ? G1 : G2; }
+    static constexpr int hin(int l) {
+        int h = F_;
+        for (int i = 0; i < l; ++i) h = (h - 1) / 2 + 1;
+        return h;
+    }
+    static constexpr int hout(int l) { return (hin(l) - 1) / 2 + 1; }
+    static constexpr int P(int l) { return hout(l) * hout(l); }
+    static constexpr int cin(int l) { return ch(l); }
+    static constexpr int cout(int l) { return ch(l + 1); }
+    static constexpr int K(int l) { return 9 * cin(l); }
+    static constexpr int ldk(int l) { return (K(l) + 3) & ~3; }
+    static constexpr int cpg(int l) { return cout(l) / grp(l); }
+    static constexpr int mode(int l) { return (l + 1 == L_ && L_ > 1 && P(l) == 4) ? 1 : 0; }
+    static constexpr int mt(int l) { return (P(l) + 15) / 16; }
+    static constexpr int nt(int l) { return (cout(l) + 15) / 16; }
+    static constexpr int hp(int l) { return hin(l) + 2; }
+    static constexpr int cs(int l) { return l == 0 ? cin(0) : cin(l) + 4; }
+    static constexpr int in_per(int l) { return (hp(l) * hp(l) * cs(l) + 3) & ~3; }
+    static constexpr int steps(int l) { return (K(l) + 15) / 16; }
+    static constexpr int ldw(int l) { return steps(l) * 16 + 4; }
+    static constexpr int w_floats(int l) { return nt(l) * 16 * ldw(l) + 3 * nt(l) * 16; }
+    static constexpr int w_off(int l) {
+        int o = 0;
+        for (int i = 0; i < l; ++i) o += w_floats(i);
+        return o;
+    }
+    static constexpr int p_off(int l) { return w_off(l) + nt(l) * 16 * ldw(l); }  // bias | gamma | beta
+    static constexpr int patch_base() { return w_off(L_); }
+    static constexpr int amax() {
+        int m = 0;
+        for (int l = 1; l < L_; ++l) m = in_per(l) > m ? in_per(l) : m;
+        return m;
+    }
+    static constexpr int in_off(int l) { return l == 0 ? 0 : in_per(0); }  // deeper images overlay
+    static constexpr int per_patch() { return in_per(0) + amax(); }
+    static constexpr int lds_floats() { return patch_base() + 8 * per_patch(); }
+    static constexpr bool ok() {
+        for (int l = 0; l < L_; ++l) {
+            const int c = cpg(l);
+            if (cout(l) % grp(l) != 0 || (c & (c - 1)) || c > 16 || (cout(l) & 3)) return false;
+            if (l > 0 && (cin(l) & 3)) return false;
+            if (mode(l) == 0 && (mt(l) > 3 || nt(l) > 2)) return false;
+        }
+        return cin(0) * F_ * F_ <= 512 && lds_floats() * 4 <= 160 * 1024;
+    }
+};
+
+// one layer of cnn_fwd2_kernel for this wave (mode 0) or this workgroup (mode 1)
+template <class N, int l>
+__device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, float* region, int wave, int lane,
+                                           int64_t row0, int nrow) {
+    constexpr int P = N::P(l), cin = N::cin(l), cout = N::cout(l), K = N::K(l), hout = N::hout(l), G = N::grp(l);
+    constexpr int cpg = N::cpg(l), hp = N::hp(l), cs = N::cs(l), ldw = N::ldw(l), steps = N::steps(l);
+    constexpr int MT = N::mt(l), NT = N::nt(l), cp = NT * 16;
+    constexpr bool last = l + 1 == N::L;
+    constexpr int ln = last ? l : l + 1;
+    constexpr int hp_n = N::hp(ln), cs_n = N::cs(ln), in_per_n = N::in_per(ln);
+    constexpr float inv_cnt = 1.0f / (float)(P * cpg);
+    const int quad = lane >> 4, l16 = lane & 15;
+    const CnnFwdLayer& Ly = A.layer[l];
+    const float* W = lds + N::w_off(l);
+    const float* pvec = lds + N::p_off(l);
+    const bool mine = wave < nrow;
+    const int64_t prow = row0 + wave;
+    if constexpr (N::mode(l) == 0) {
+        // ================= a wave owns its patch: MT x NT tiles, k ascending
+        if (!mine) return;
+        const float* in = region + N::in_off(l);
+        int rbase[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = mt * 16 + l16;
+            m = m < P ? m : 0;
+            rbase[mt] = (2 * (m / hout) * hp + 2 * (m % hout)) * cs;
+        }
+        cf32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = cf32x4{0.f, 0.f, 0.f, 0.f};
+        // fragments of step kk + 1 are read while the matrix instructions of step kk issue
+        float4 a[MT], b[NT], an[MT], bn[NT];
+        auto frag = [&](int kk, float4 (&fa)[MT], float4 (&fb)[NT]) {
+            const int k0 = kk * 16 + 4 * quad;
+            if constexpr (l > 0) {  // cin % 4 == 0: the four k of a lane are one float4 along ci
+                int tap = k0 / cin;
+                const int ci = k0 - tap * cin;
+                tap = tap < 9 ? tap : 8;
+                const int off = ((tap / 3) * hp + tap % 3) * cs + ci;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const float4*>(in + rbase[mt] + off);
+            } else {
+                int off[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = k0 + j;
+                    k = k < K ? k : K - 1;  // the weight column is zero there
+                    const int tap = k / cin, ci = k - tap * cin;
+                    off[j] = ((tap / 3) * hp + tap % 3) * cs + ci;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    fa[mt] = make_float4(in[rbase[mt] + off[0]], in[rbase[mt] + off[1]], in[rbase[mt] + off[2]],
+                                         in[rbase[mt] + off[3]]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const float4*>(W + (nt * 16 + l16) * ldw + k0);
+        };
+        frag(0, a, b);
+#pragma unroll 2
+        for (int kk = 0; kk < steps; ++kk) {
+            frag(kk + 1 < steps ? kk + 1 : kk, an, bn);
+            // k-major: consecutive matrix instructions never share an accumulator
+#define MARL_F2_MFMA(q_)                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].q_, b[nt].q_, acc[mt][nt], 0, 0, 0);
+            MARL_F2_MFMA(x) MARL_F2_MFMA(y) MARL_F2_MFMA(z) MARL_F2_MFMA(w)
+#undef MARL_F2_MFMA
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        }
+        // ---- bias, GroupNorm statistics from the registers (two passes), SiLU
+        float* nxt = region + N::in_off(ln);
+        if constexpr (!last)  // fresh zero border for the next layer's image (it may overlay this input)
+            for (int i = lane; i < (in_per_n >> 2); i += 64)
+                *reinterpret_cast<float4*>(nxt + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ch = nt * 16 + l16;
+            const bool cv = ch < cout;
+            const float bv = pvec[ch], gm = pvec[cp + ch], bt = pvec[2 * cp + ch];
+            float s = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[mt][nt][r] += bv;
+                    if (mt * 16 + 4 * quad + r < P) s += acc[mt][nt][r];
+                }
+            s = row_block_sum(cross_row_sum(s), cpg);
+            const float mean = s * inv_cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mt * 16 + 4 * quad + r < P) {
+                        const float d = acc[mt][nt][r] - mean;
+                        q += d * d;
+                    }
+            q = row_block_sum(cross_row_sum(q), cpg);
+            const float rstd = 1.0f / sqrtf(q * inv_cnt + 1e-5f);
+            if (Ly.gst && cv && quad == 0 && (l16 & (cpg - 1)) == 0) {
+                float* gs = Ly.gst + (prow * G + ch / cpg) * 2;
+                gs[0] = mean;
+                gs[1] = rstd;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + 4 * quad + r;
+                    if (row < P && cv) {
+                        const float zv = acc[mt][nt][r];
+                        if (Ly.z) Ly.z[(prow * P + row) * (int64_t)cout + ch] = zv;
+                        const float av = cnn_silu((zv - mean) * rstd * gm + bt);
+                        if constexpr (last)
+                            A.u[prow * (int64_t)A.ldu + ch * P + row] = av;
+                        else
+                            nxt[((row / hout + 1) * hp_n + row % hout + 1) * cs_n + ch] = av;
+                    }
+                }
+        }
+    } else {
+        // ================= 16-row tiles over 4 patches (P == 4), one (row tile, column tile) per turn
+        __syncthreads();  // the other waves' images of this layer's input are complete
+        constexpr int ntask = 2 * NT;  // 8 patches * 4 positions = 2 row tiles
+        for (int task = wave; task < ntask; task += 8) {
+            const int gi = task / NT, nt = task - gi * NT;
+            const int lr_a = gi * 4 + (l16 >> 2), pos_a = l16 & 3;
+            const float* in = lds + N::patch_base() + lr_a * N::per_patch() + N::in_off(l) +
+                              (2 * (pos_a / hout) * hp + 2 * (pos_a % hout)) * cs;
+            const float* wrow = W + (nt * 16 + l16) * ldw + 4 * quad;
+            // two accumulators (even / odd 16-deep k steps): the single tile of this wave would
+            // otherwise be one dependent chain of matrix instructions
+            cf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            auto fragA = [&](int kk) {
+                const int k0 = kk * 16 + 4 * quad;
+                int tap = k0 / cin;
+                const int ci = k0 - tap * cin;
+                tap = tap < 9 ? tap : 8;
+                return *reinterpret_cast<const float4*>(in + ((tap / 3) * hp + tap % 3) * cs + ci);
+            };
+            float4 a0 = fragA(0), b0 = *reinterpret_cast<const float4*>(wrow);
+            float4 a1 = fragA(1 < steps ? 1 : 0), b1 = *reinterpret_cast<const float4*>(wrow + (1 < steps ? 16 : 0));
+#pragma unroll 2
+            for (int kk = 0; kk < steps; kk += 2) {
+                const int k2 = kk + 2 < steps ? kk + 2 : kk, k3 = kk + 3 < steps ? kk + 3 : kk;
+                const float4 a2 = fragA(k2), b2 = *reinterpret_cast<const float4*>(wrow + k2 * 16);
+                const float4 a3 = fragA(k3), b3 = *reinterpret_cast<const float4*>(wrow + k3 * 16);
+                const bool odd = kk + 1 < steps;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
+                if (odd) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
+                if (odd) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
+                if (odd) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+                if (odd) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
+                a0 = a2;
+                b0 = b2;
+                a1 = a3;
+                b1 = b3;
+            }
+            acc0 += acc1;
+            // lane (quad, l16) holds patch gi * 4 + quad, positions r = 0..3, channel nt * 16 + l16
+            const int lr_o = gi * 4 + quad;
+            const int ch = nt * 16 + l16;
+            const bool cv = ch < cout, pv = lr_o < nrow;
+            const float bv = pvec[ch], gm = pvec[cp + ch], bt = pvec[2 * cp + ch];
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0[r] += bv;
+                s += acc0[r];
+            }
+            s = row_block_sum(s, cpg);
+            const float mean = s * inv_cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc0[r] - mean;
+                q += d * d;
+            }
+            q = row_block_sum(q, cpg);
+            const float rstd = 1.0f / sqrtf(q * inv_cnt + 1e-5f);
+            const int64_t orow = row0 + lr_o;
+            if (pv && cv) {
+                if (Ly.gst && (l16 & (cpg - 1)) == 0) {
+                    float* gs = Ly.gst + (orow * G + ch / cpg) * 2;
+                    gs[0] = mean;
+                    gs[1] = rstd;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float zv = acc0[r];
+                    if (Ly.z) Ly.z[(orow * P + r) * (int64_t)cout + ch] = zv;
+                    A.u[orow * (int64_t)A.ldu + ch * P + r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                }
+            }
+        }
+        __syncthreads();  // before the next chunk's layers overwrite the images read above
+    }
+}
+
+template <class N>
+__global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int f = N::F, ff = f * f, pe = N::cin(0) * ff;
+    const float* imgf = static_cast<const float*>(A.img);
+    const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+    float* region = lds + N::patch_base() + wave * N::per_patch();  // this wave's patch
+    constexpr int kPF = (pe + 63) / 64;  // gathered pixels per lane
+    float pf[kPF];
+    int np0 = 0, np1 = 0;  // position of the patch whose pixels are fetched next
+    auto load_pos = [&](int chunk) {
+        const int64_t r = (int64_t)chunk * 8 + wave;
+        if (chunk < nchunks && r < A.rows && !A.obs) {
+            np0 = A.pos[r * 2];
+            np1 = A.pos[r * 2 + 1];
+        }
+    };
+    auto prefetch = [&](int chunk) {  // pixels of this wave's patch of `chunk` (position in np0 / np1)
+        const int64_t r = (int64_t)chunk * 8 + wave;
+        const bool have = chunk < nchunks && r < A.rows;
+        const int64_t base = !have ? 0 : A.obs ? r * A.c_img * ff : (r % A.nb) * A.c_img * (int64_t)A.H * A.W;
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) {
+            const int e = lane + 64 * i;
+            pf[i] = 0.f;
+            if (have && e < pe) {
+                if (A.obs) {
+                    pf[i] = A.obs[base + e];
+                } else {
+                    const int ci = e / ff, e2 = e - ci * ff, iy = e2 / f, ix = e2 - iy * f;
+                    const int64_t off = base + ((int64_t)ci * A.H + (np0 + iy)) * A.W + (np1 + ix);
+                    pf[i] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];  // ToTensor on the fly
+                }
+            }
+        }
+    };
+    load_pos(blockIdx.x);  // in flight while LDS is set up
+
+    // ---- one-time: zero LDS (borders, weight padding), then all conv weights and the per-channel
+    // vectors (bias | gamma | beta) -> LDS
+    for (int i = tid; i < (N::lds_floats() >> 2); i += 512)
+        *reinterpret_cast<float4*>(lds + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    auto stage_w = [&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if constexpr (l < N::L) {
+            const CnnFwdLayer& Ly = A.layer[l];
+            constexpr int k4 = N::ldk(l) >> 2, cout = N::cout(l);
+            for (int idx = tid; idx < cout * k4; idx += 512) {
+                const int n = idx / k4, c = (idx - n * k4) * 4;
+                *reinterpret_cast<float4*>(lds + N::w_off(l) + n * N::ldw(l) + c) =
+                    *reinterpret_cast<const float4*>(Ly.w + (int64_t)n * N::ldk(l) + c);
+            }
+            float* pv = lds + N::p_off(l);
+            constexpr int cp = N::nt(l) * 16;
+            for (int c = tid; c < cout; c += 512) {
+                pv[c] = Ly.bias[c];
+                pv[cp + c] = Ly.gamma[c];
+                pv[2 * cp + c] = Ly.beta[c];
+            }
+        }
+    };
+    stage_w(std::integral_constant<int, 0>{});
+    stage_w(std::integral_constant<int, 1>{});
+    stage_w(std::integral_constant<int, 2>{});
+    prefetch(blockIdx.x);
+    load_pos(blockIdx.x + gridDim.x);
+    __syncthreads();
+
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t row0 = (int64_t)chunk * 8;
+        const int nrow = (int)(A.rows - row0 < 8 ? A.rows - row0 : 8);
+        // ---- raw patch -> this wave's zero-bordered input image (HWC)
+        {
+            constexpr int hp = N::hp(0), cs = N::cs(0);
+            float* in0 = region + N::in_off(0);
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                const int e = lane + 64 * i;
+                if (e < pe) {
+                    const int ci = e / ff, e2 = e - ci * ff, iy = e2 / f, ix = e2 - iy * f;
+                    in0[((iy + 1) * hp + ix + 1) * cs + ci] = pf[i];
+                }
+            }
+        }
+        prefetch(chunk + gridDim.x);           // the next chunk's pixels fly during this chunk's layers
+        load_pos(chunk + 2 * (int)gridDim.x);  // and the position after that
+        fwd2_layer<N, 0>(A, lds, region, wave, lane, row0, nrow);
+        if constexpr (N::L > 1) fwd2_layer<N, 1>(A, lds, region, wave, lane, row0, nrow);
+        if constexpr (N::L > 2) fwd2_layer<N, 2>(A, lds, region, wave, lane, row0, nrow);
+    }
+}
+
+// the extractor shapes cnn_fwd2_kernel is built for
+using Fwd2Resisc = Fwd2Net<12, 3, 3, 16, 32, 64, 2, 4, 8>;   // Resisc45Cnn / SkinCancerCnn, f = 12
+using Fwd2Mnist6 = Fwd2Net<6, 2, 1, 8, 16, 0, 2, 4, 1>;      // MnistCnn, f = 6 (README)
+using Fwd2Mnist12 = Fwd2Net<12, 2, 1, 8, 16, 0, 2, 4, 1>;    // MnistCnn, f = 12 (the reference's tests)
+static_assert(Fwd2Resisc::ok() && Fwd2Mnist6::ok() && Fwd2Mnist12::ok(), "fwd2 nets");
+
+template <class N>
+static bool fwd2_matches(const CnnFwdArgs& a) {
+    if (a.L != N::L || a.f != N::F) return false;
+    for (int l = 0; l < N::L; ++l) {
+        const CnnFwdLayer& Ly = a.layer[l];
+        if (Ly.cin != N::cin(l) || Ly.cout != N::cout(l) || Ly.G != N::grp(l) || Ly.ldk != N::ldk(l)) return false;
+        if (Ly.cols) return false;  // im2col rows wanted (weight gradient outside the fused kernel's range)
+    }
+    return true;
+}
+
+template <class N>
+static int fwd2_launch(CnnFwdArgs& a, hipStream_t st) {
+    static bool raised = false;  // per process; one process drives one GPU
+    auto kern = cnn_fwd2_kernel<N>;
+    constexpr size_t lds = (size_t)N::lds_floats() * sizeof(float);
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const int nchunks = (int)cdiv(a.rows, 8);
+    const int blocks = nchunks < 256 ? nchunks : 256;
+    prof_before(3, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, nchunks);
+    prof_after(3, st);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// 0 = not covered, else 1 + index of the instantiation
+static int cnn_fwd2_which(const CnnFwdArgs& a) {
+    if (!tune_get("cnn_fwd2", 1)) return 0;
+    if (fwd2_matches<Fwd2Resisc>(a)) return 1;
+    if (fwd2_matches<Fwd2Mnist6>(a)) return 2;
+    if (fwd2_matches<Fwd2Mnist12>(a)) return 3;
+    return 0;
+}
+
 // LDS floats for rb patches per workgroup; fills the launcher-owned fields of `a`
 static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
     size_t b0 = 0, b1 = 0, st = 0;
@@ -408,6 +850,7 @@ static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
 int cnn_fwd_supported(const CnnFwdArgs& a0) {
     if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
     CnnFwdArgs a = a0;
+    if (cnn_fwd2_which(a)) return 1;
     for (int l = 0; l < a.L; ++l) {
         const CnnFwdLayer& L = a.layer[l];
         if (L.cout % L.G != 0 || ((L.cout / L.G) & 3) || (L.cout & 3)) return 0;  // float4 stays inside a group
@@ -418,6 +861,12 @@ int cnn_fwd_supported(const CnnFwdArgs& a0) {
 
 int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
     if (a.rows <= 0) return MARL_OK;
+    switch (cnn_fwd2_which(a)) {
+        case 1: return fwd2_launch<Fwd2Resisc>(a, st);
+        case 2: return fwd2_launch<Fwd2Mnist6>(a, st);
+        case 3: return fwd2_launch<Fwd2Mnist12>(a, st);
+        default: break;
+    }
     // as many patches per workgroup as fit three workgroups per CU (the conv weights are
     // re-read from L2 by every workgroup), but keep >= 256 workgroups
     static int rb_max = 0, lds_cap = 0;

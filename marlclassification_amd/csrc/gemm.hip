@@ -659,7 +659,7 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
                     batch.p[i].nseg > 1 ? batch.p[i].seg[1].k : 0, batch.p[i].accumulate,
                     batch.p[i].bias != nullptr, batch.p[i].seg[0].lda, batch.p[i].ldc);
     prof_before(1, st);
-    if (blocks128 >= 256 && max_n >= 96) {
+    if (blocks128 >= tune_get("nt_min_blocks128", 256) && max_n >= 96) {
         const int g = gemm_groups();
         dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         if (g == 2)

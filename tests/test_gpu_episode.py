@@ -2,8 +2,8 @@
 vectors generated from the real reference and against the CPU oracle.
 
 Tolerances (BASELINE.json north_star): agent positions and sampled action indices
-bit-exact; logits / log-probs / values within 1e-5 fp32; gradients within 1e-4 of the
-tensor's scale."""
+bit-exact; logits / log-probs / values within 1e-5 fp32 ABSOLUTE; gradients within 1e-4 of the
+tensor's scale; one Adam step within 1e-3 of lr per weight."""
 import os
 
 import pytest
@@ -38,9 +38,10 @@ def _maxerr(a, b):
 
 
 def _relerr(a, b):
-    """max |a - b| in units of max(1, max|b|): 1e-5 absolute for O(1) logits, 1e-5 of the
-    tensor's scale for the trained checkpoint whose logits reach ~15."""
-    return _maxerr(a, b) / max(1.0, b.abs().max().item())
+    """max |a - b|, ABSOLUTE (north_star: logits within 1e-5 fp32).  Achieved on the fixtures
+    (tests/test_gpu_round2.py::test_record_achieved_errors, DESIGN.md section 2): <= 2e-6 for
+    O(1) logits, 7.2e-6 for the trained checkpoint whose logits reach 14.6."""
+    return _maxerr(a, b)
 
 
 @pytest.mark.parametrize("tag", ["g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt"])
@@ -143,7 +144,8 @@ def test_backward_and_adam_match_reference(device, tag):
     # the first Adam step moves every weight by ~lr * sign(g); compare the update itself
     upd, ref_upd = flat_p.cpu() - ref_before, ref_after - ref_before
     big = th.cat([g.grad(k).flatten() for k in names]).abs() > 1e-6
-    assert (upd[big] - ref_upd[big]).abs().max().item() <= 0.02 * g.lr
+    # achieved: <= 1e-4 of lr on every fixture
+    assert (upd[big] - ref_upd[big]).abs().max().item() <= 1e-3 * g.lr
 
 
 def test_backward_resisc_dims_gradient_samples(device):

@@ -50,8 +50,7 @@ def _check_against_oracle(eng, cfg, device, params, img, y, inp, ns, img_dev=Non
     assert th.equal(out.step_pos.cpu(), tr.step_pos), "agent positions differ"
     errs = {"preds": _maxerr(out.step_preds, tr.step_preds), "logp": _maxerr(out.step_log_probas, tr.step_log_probas),
             "values": _maxerr(out.step_values, tr.step_values)}
-    scale = max(1.0, tr.step_preds.abs().max().item())
-    assert max(errs.values()) <= ATOL * scale, errs
+    assert max(errs.values()) <= ATOL, errs
     gp, gl, gv, sc, _ = eng.a2c_loss(out, y.to(device), 0.99)
     assert abs(sc[0].item() - lo.loss.item()) <= 5e-5 * max(1.0, abs(lo.loss.item()))
     g_out = {k: th.full_like(v, float("nan"), device=device) for k, v in params.items()}
@@ -441,7 +440,7 @@ def test_two_rank_hip_trainer_matches_big_batch_update(device, exact):
             upd = sd[k] - g.params[k]
             big = g.grad(k).abs() > 1e-6
             if big.any():
-                assert (upd[big] - ref_upd[big]).abs().max().item() <= 0.02 * g.lr, k
+                assert (upd[big] - ref_upd[big]).abs().max().item() <= 1e-3 * g.lr, k
 
 
 # ---- achieved errors per fixture (recorded for DESIGN.md) ------------------------------------------
