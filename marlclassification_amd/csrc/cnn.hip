@@ -684,6 +684,10 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
     float* region = lds + N::patch_base() + wave * N::per_patch();  // this wave's patch
     constexpr int kPF = (pe + 63) / 64;  // gathered pixels per lane
     float pf[kPF];
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(A.ts);
+#endif
+    MARL_TS();
     int np0 = 0, np1 = 0;  // position of the patch whose pixels are fetched next
     auto load_pos = [&](int chunk) {
         const int64_t r = (int64_t)chunk * 8 + wave;
@@ -722,11 +726,20 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
         constexpr int l = decltype(lc)::value;
         if constexpr (l < N::L) {
             const CnnFwdLayer& Ly = A.layer[l];
-            constexpr int k4 = N::ldk(l) >> 2, cout = N::cout(l);
-            for (int idx = tid; idx < cout * k4; idx += 512) {
+            constexpr int k4 = N::ldk(l) >> 2, cout = N::cout(l), nld = (cout * k4 + 511) / 512;
+            // all loads of a layer in flight before the first LDS store (one L2 round trip, not nld)
+            float4 wv[nld];
+#pragma unroll
+            for (int i = 0; i < nld; ++i) {
+                const int idx = tid + 512 * i;
+                wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < cout * k4) wv[i] = *reinterpret_cast<const float4*>(Ly.w + 4 * idx);
+            }
+#pragma unroll
+            for (int i = 0; i < nld; ++i) {
+                const int idx = tid + 512 * i;
                 const int n = idx / k4, c = (idx - n * k4) * 4;
-                *reinterpret_cast<float4*>(lds + N::w_off(l) + n * N::ldw(l) + c) =
-                    *reinterpret_cast<const float4*>(Ly.w + (int64_t)n * N::ldk(l) + c);
+                if (idx < cout * k4) *reinterpret_cast<float4*>(lds + N::w_off(l) + n * N::ldw(l) + c) = wv[i];
             }
             float* pv = lds + N::p_off(l);
             constexpr int cp = N::nt(l) * 16;
@@ -742,9 +755,12 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
     stage_w(std::integral_constant<int, 2>{});
     prefetch(blockIdx.x);
     load_pos(blockIdx.x + gridDim.x);
+    MARL_TS();
     __syncthreads();
+    MARL_TS();
 
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        MARL_TS();
         const int64_t row0 = (int64_t)chunk * 8;
         const int nrow = (int)(A.rows - row0 < 8 ? A.rows - row0 : 8);
         // ---- raw patch -> this wave's zero-bordered input image (HWC)
@@ -762,9 +778,13 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
         }
         prefetch(chunk + gridDim.x);           // the next chunk's pixels fly during this chunk's layers
         load_pos(chunk + 2 * (int)gridDim.x);  // and the position after that
+        MARL_TS();
         fwd2_layer<N, 0>(A, lds, region, wave, lane, row0, nrow);
+        MARL_TS();
         if constexpr (N::L > 1) fwd2_layer<N, 1>(A, lds, region, wave, lane, row0, nrow);
+        MARL_TS();
         if constexpr (N::L > 2) fwd2_layer<N, 2>(A, lds, region, wave, lane, row0, nrow);
+        MARL_TS();
     }
 }
 
@@ -797,10 +817,19 @@ static int fwd2_launch(CnnFwdArgs& a, hipStream_t st) {
     }
     const int nchunks = (int)cdiv(a.rows, 8);
     const int blocks = nchunks < 256 ? nchunks : 256;
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts2 = nullptr;
+    static int calls2 = 0;
+    const int rec2 = ts_begin(&d_ts2, calls2++);
+    a.ts = rec2 ? d_ts2 : nullptr;
+#endif
     prof_before(3, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, nchunks);
     prof_after(3, st);
     MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec2) ts_report("cnn_fwd2", d_ts2, 8);
+#endif
     return MARL_OK;
 }
 

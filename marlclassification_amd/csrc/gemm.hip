@@ -762,7 +762,7 @@ static TnPlan tn_plan(int ni, int nj, int64_t rows) {
     // target turns into hundreds of row slabs and the slab reduction costs more than the product
     p.bm = (ni >= 96 && nj >= 96 && cdiv(ni, 128) * cdiv(nj, 128) >= 4) ? 128 : 64;
     const int64_t tiles = cdiv(ni, p.bm) * cdiv(nj, p.bm);
-    int64_t s = cdiv(768, tiles);
+    int64_t s = cdiv(tune_get("tn_target_wgs", 768), tiles);
     const int64_t max_s = cdiv(rows, 4 * BK);  // at least 4 K tiles per split
     if (s > max_s) s = max_s;
     if (s > 512) s = 512;
@@ -810,7 +810,7 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
                 (long long)rows, p.bm, p.splits, colsum_out != nullptr);
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
     int gx = 0, gy = 0, gz = 0;
-    if (xcd_map_enabled()) {
+    if (xcd_map_enabled() || tune_get("tn_xcd", 0)) {
         gx = (int)grid.x;
         gy = (int)grid.y;
         gz = (int)grid.z;
