@@ -19,7 +19,20 @@
  *     ZERO-FILLED once by the caller before first use (padding columns inside
  *     them are never written and are read as zeros by the matrix kernels);
  *   - return value: 0 on success, a negative MARL_E* code otherwise; nothing
- *     throws across the ABI.  marl_last_error() gives a thread-local message.
+ *     throws across the ABI.  marl_last_error() gives a thread-local message;
+ *   - one process drives one GPU (the launch contract of bench.py / train.py): the one-off
+ *     kernel attributes (LDS opt-in), the profiling hook and the tuning knobs are per-process
+ *     state, not per-device or per-thread;
+ *   - data parallelism needs no entry point here: the gradients land in ONE flat fp32 buffer
+ *     (the caller's, see marl_adam_step) and the caller all-reduces that buffer with RCCL
+ *     (torch.distributed backend "nccl" in parallel.py) between marl_episode_backward and
+ *     marl_adam_step, passing 1 / world_size as grad_scale.  SURVEY 8(b) sketched a
+ *     marl_allreduce_grads(comm, ...) wrapper; it would only forward to ncclAllReduce, so the
+ *     collective stays with the host framework that owns the communicator;
+ *   - size limits: GEMM operands are addressed with 32-bit byte offsets from a 64-bit base,
+ *     so rows * leading_dimension of any activation matrix must stay below 2^30 floats
+ *     (e.g. Ns * Na * Nb < 2^20 rows at 4 * n_b = 1024 gate columns: 4095 images per GPU at
+ *     the RESISC45 16-agent / 16-step configuration).
  */
 #ifndef MARL_HIP_H
 #define MARL_HIP_H
