@@ -314,6 +314,9 @@ struct PanelFwdBatch {
     // rows (one wave per row) - an independent small kernel riding along in the same launch
     int has_sample, panel_blocks;
     SampleArgs sample;
+#ifdef MARL_KERNEL_TS
+    long long* ts;  // phase timestamps of one workgroup (debug builds only)
+#endif
 };
 int panel_supported(int k0, int n0, int n1);
 int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st);

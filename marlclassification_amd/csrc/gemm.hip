@@ -809,8 +809,11 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         fprintf(stderr, "[gemm_tn] ni=%d nj=%d rows=%lld bm=%d splits=%d colsum=%d\n", ni, nj,
                 (long long)rows, p.bm, p.splits, colsum_out != nullptr);
     dim3 grid((unsigned)cdiv(ni, p.bm), (unsigned)cdiv(nj, p.bm), (unsigned)p.splits);
+    // XCD-ordered tiles by default: all tiles of a row slab run on one XCD and read its A / B row
+    // panels through that XCD's L2 once (measured: FETCH_SIZE 706 -> 292 MB per launch = 1.07x the
+    // algorithmic bytes, same duration - the kernel is matrix-pipe bound)
     int gx = 0, gy = 0, gz = 0;
-    if (xcd_map_enabled() || tune_get("tn_xcd", 0)) {
+    if (xcd_map_enabled() || tune_get("tn_xcd", 1)) {
         gx = (int)grid.x;
         gy = (int)grid.y;
         gz = (int)grid.z;

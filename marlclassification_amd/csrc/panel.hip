@@ -142,6 +142,10 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
     if (m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int quad = lane >> 4, l16 = lane & 15;
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(B.ts);
+#endif
+    MARL_TS();
     float* X = lds;
     float* Y = lds + B.off_panel1;
     float* part = lds + B.off_part;
@@ -212,7 +216,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
             }
         }
     }
+    MARL_TS();
     lds_barrier();
+    MARL_TS();
 
     for (int l = 0; l < P.nlayers; ++l) {
         const PanelLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
@@ -233,7 +239,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         const int kend = kbeg + kper < K16 ? kbeg + kper : K16;
         f32x4 acc[2];
         if (active) panel_gemm(acc, in, stride, K, Lr.w, Lr.ldw, n, j, kbeg, kend, lane);
+        MARL_TS();
         panel_ksum(acc, part, nt, ks, j, s, lane, active);
+        MARL_TS();
 
         // z = acc + bias -> output panel in LDS (and global, kept for backward)
         const int ys = panel_stride(n), n16 = (n + 15) & ~15;
@@ -252,7 +260,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                 }
             }
         }
+        MARL_TS();
         lds_barrier();
+        MARL_TS();
         // LayerNorm + SiLU: wave w owns rows w, w + nwaves, ...; a row lives in registers (<= 6
         // columns per lane), two-pass statistics with VALU wave reductions, result written
         // over the LDS panel (next layer's input) and to global.
@@ -307,7 +317,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                 }
             }
         }
+        MARL_TS();
         lds_barrier();
+        MARL_TS();
     }
 }
 
@@ -378,6 +390,12 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
         raised = true;
     }
     const unsigned pblocks = (unsigned)cdiv(mmax, kPanelRows);
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts = nullptr;
+    static int calls = 0;
+    const int rec = ts_begin(&d_ts, calls++);
+    b.ts = rec ? d_ts : nullptr;
+#endif
     prof_before(4, st);
     if (b.has_sample && b.count == 1) {
         b.panel_blocks = (int)pblocks;
@@ -390,6 +408,12 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
     }
     prof_after(4, st);
     MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec) {
+        fprintf(stderr, "[ts] panel_fwd count %d sample %d waves %d lds %zu\n", b.count, b.has_sample, waves, lds);
+        ts_report("panel_fwd", d_ts, waves);
+    }
+#endif
     return MARL_OK;
 }
 
