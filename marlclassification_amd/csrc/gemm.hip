@@ -579,7 +579,10 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     GemmBatch batch = batch_in;
     batch.gx = (int)grid.x;
     batch.gy = (int)grid.y;
-    batch.xcd_map = xcd_map_enabled();
+    // XCD-ordered tiles (column block fastest inside an XCD's chunk) when the launch is ONE
+    // product: its row panels are then read through one L2 once.  Batched launches of unequal
+    // problems would load the XCDs unevenly (measured slower), they keep the plain order.
+    batch.xcd_map = xcd_map_enabled() || (batch.count == 1 && !LSTM && tune_get("nt_xcd", 1));
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     constexpr size_t lds = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, GROUPS>;
