@@ -206,6 +206,24 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
+    // LSTM: the previous cell state and the biases are only needed by the epilogue; issuing their
+    // loads here keeps them in flight behind the whole K loop instead of starting a dependent
+    // HBM round trip when every workgroup of the launch reaches its epilogue at the same time
+    float cprev[LSTM ? 16 : 1];
+    float lbias[LSTM ? 4 : 1];
+    if (LSTM) {
+        const int unit_ = n0 + (lane & 31);
+        const int uc_ = unit_ < N ? unit_ : N - 1;
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) lbias[LSTM ? g_ : 0] = P.bias[g_ * N + uc_];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row_ = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            row_ = row_ < M ? row_ : M - 1;
+            cprev[LSTM ? r : 0] = P.c_prev[(size_t)row_ * P.ld_state + uc_];
+        }
+    }
+
     MARL_SET_SEG(0)
     MARL_LOAD_TILE(0)
     if (GROUPS == 1) {
@@ -283,8 +301,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
     } else {
         const int unit = n0 + col_l;
         if (unit < N) {
-            const float bi = P.bias[unit], bf = P.bias[N + unit], bg = P.bias[2 * N + unit],
-                        bo = P.bias[3 * N + unit];
+            const float bi = lbias[0], bf = lbias[LSTM ? 1 : 0], bg = lbias[LSTM ? 2 : 0], bo = lbias[LSTM ? 3 : 0];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + row_h;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
                     const float gg = tanh_fast(acc[0][2][r] + bg);
                     const float go = sigmoid_acc(acc[0][3][r] + bo);
                     const size_t so = (size_t)row * P.ld_state + unit;
-                    const float cn = gf * P.c_prev[so] + gi * gg;
+                    const float cn = gf * cprev[LSTM ? r : 0] + gi * gg;
                     P.c_next[so] = cn;
                     P.h_next[so] = go * tanh_fast(cn);
                     if (P.gates) {
