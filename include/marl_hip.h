@@ -27,7 +27,7 @@
  *     (the caller's, see marl_adam_step) and the caller all-reduces that buffer with RCCL
  *     (torch.distributed backend "nccl" in parallel.py) between marl_episode_backward and
  *     marl_adam_step, passing 1 / world_size as grad_scale.  SURVEY 8(b) sketched a
- *     marl_allreduce_grads(comm, ...) wrapper; it would only forward to ncclAllReduce, so the
+ *     "marl_allreduce_grads" wrapper taking a communicator; it would only forward to ncclAllReduce, so the
  *     collective stays with the host framework that owns the communicator;
  *   - size limits: GEMM operands are addressed with 32-bit byte offsets from a 64-bit base,
  *     so rows * leading_dimension of any activation matrix must stay below 2^30 floats
