@@ -1,13 +1,12 @@
 """``python -m marlclassification_amd`` - the reference's command line (__main__.py:19-417):
 ``[-a N --step T --cuda --run-id ID] train [options]``, same flags, defaults and action
-syntax (``[[1,0],[-1,0],...]``).  ``test`` / ``infer`` / visualisation are outside the
-hot-path scope of this repository."""
+syntax (``[[1,0],[-1,0],...]``), with the ``train``, ``test`` and ``infer`` modes."""
 
 import argparse
 import re
 from os.path import abspath, dirname, join
 
-from .config import MainConfig, ModelConfig, TrainConfig
+from .config import EvalConfig, InferConfig, MainConfig, ModelConfig, TrainConfig
 from .networks.vision import CNN_BY_NAME
 
 _TRAIN_FLAGS = (
@@ -55,6 +54,19 @@ def build_parser() -> argparse.ArgumentParser:
     t.add_argument("--res-folder", type=str, dest="res_folder",
                    default=abspath(join(dirname(abspath(__file__)), "..", "resources")))
     t.add_argument("-o", "--output-dir", type=str, required=True, dest="output_dir")
+    e = sub.add_parser("test")  # reference __main__.py:217-258
+    e.add_argument("--batch-size", type=int, default=8, dest="batch_size")
+    e.add_argument("--dataset-path", type=str, required=True, dest="dataset_path")
+    e.add_argument("--img-size", type=int, default=28, dest="img_size")
+    e.add_argument("--json-path", type=str, required=True, dest="json_path")
+    e.add_argument("--state-dict-path", type=str, required=True, dest="state_dict_path")
+    e.add_argument("-o", "--output-dir", type=str, required=True, dest="output_dir")
+    i = sub.add_parser("infer")  # reference __main__.py:263-300
+    i.add_argument("--images", type=str, nargs="+", required=True, dest="infer_images")
+    i.add_argument("--json-path", type=str, required=True, dest="json_path")
+    i.add_argument("--state-dict-path", type=str, required=True, dest="state_dict_path")
+    i.add_argument("--class2idx", type=str, required=True, dest="class_to_idx")
+    i.add_argument("-o", "--output-image-dir", type=str, required=True, dest="output_image_dir")
     t.add_argument("--exact-standardize", action="store_true", dest="exact_standardize",
                    help="multi-GPU: global advantage statistics (update == single-GPU big batch)")
     return p
@@ -79,6 +91,23 @@ def main(argv=None) -> None:
             gamma=args.gamma,
         )
         train_main(main_config, model_config, train_config, exact_standardize=args.exact_standardize)
+    elif args.main_choice == "test":
+        from .eval import eval_main
+
+        eval_main(main_config, EvalConfig(
+            img_size=args.img_size, state_dict_path=args.state_dict_path, batch_size=args.batch_size,
+            json_path=args.json_path, dataset_path=args.dataset_path, output_dir=args.output_dir))
+    elif args.main_choice == "infer":
+        import os
+
+        from .infer import infer_main
+
+        if os.path.exists(args.output_image_dir) and not os.path.isdir(args.output_image_dir):
+            raise NotADirectoryError(f'"{args.output_image_dir}" is not a directory.')
+        os.makedirs(args.output_image_dir, exist_ok=True)
+        infer_main(main_config, InferConfig(
+            state_dict_path=args.state_dict_path, json_path=args.json_path, images_path=args.infer_images,
+            output_dir=args.output_image_dir, class_to_idx=args.class_to_idx))
 
 
 if __name__ == "__main__":

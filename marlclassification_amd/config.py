@@ -88,3 +88,11 @@ class EvalConfig(BaseModel):
     json_path: str
     dataset_path: str
     output_dir: str
+
+
+class InferConfig(BaseModel):
+    state_dict_path: str
+    json_path: str
+    images_path: List[str]
+    output_dir: str
+    class_to_idx: str

@@ -5,9 +5,17 @@ syncs per iteration (reference training/trainer.py:119-135).  Reporting code, no
 timed path."""
 
 from collections import deque
-from typing import Deque, Optional
+from os.path import join
+from typing import Any, Deque, Mapping, Optional
 
 import torch as th
+
+
+def format_metric(metric: th.Tensor, class_map: Mapping[Any, int]) -> str:
+    """'"class" : 12.3%' per class, in index order (reference metrics.py:10-18)."""
+    names = {idx: name for name, idx in class_map.items()}
+    values = metric.detach().cpu().tolist()
+    return ", ".join(f'"{names[i]}" : {v * 100.0:.1f}%' for i, v in enumerate(values))
 
 
 class ConfusionMeter:
@@ -34,6 +42,27 @@ class ConfusionMeter:
         allreduce_confusion(cm, group)
         self.__window.clear()
         self.__window.append(cm)
+
+    def save_conf_matrix(self, epoch: int, output_dir: str, stage: str) -> str:
+        """Row-normalised confusion matrix as ``confusion_matrix_epoch_{e}_{stage}.png``
+        (reference metrics.py:110-129); host-side reporting, matplotlib imported on use."""
+        import matplotlib
+
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+
+        cm = self.conf_mat().to(th.float).cpu()
+        rows = cm.sum(dim=1, keepdim=True)
+        shown = th.where(rows > 0, cm / rows.clamp(min=1.0), th.zeros_like(cm))
+        fig, ax = plt.subplots()
+        fig.colorbar(ax.matshow(shown.tolist(), cmap="plasma"))
+        ax.set_title(f"confusion matrix epoch {epoch} - {stage}")
+        ax.set_ylabel("True Label")
+        ax.set_xlabel("Predicated Label")
+        path = join(output_dir, f"confusion_matrix_epoch_{epoch}_{stage}.png")
+        fig.savefig(path)
+        plt.close(fig)
+        return path
 
     def precision(self) -> th.Tensor:
         cm = self.conf_mat().to(th.float)

@@ -132,7 +132,16 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
             m["eval_prec"] = conf.precision().mean().item()
             m["eval_recs"] = conf.recall().mean().item()
             print(f"epoch {e}: " + ", ".join(f"{k}={v:.4f}" for k, v in m.items()), flush=True)
+            conf.save_conf_matrix(e, output_dir, "eval")  # reference train.py:134
             th.save(nn_models.state_dict(), join(model_dir, f"nn_models_epoch_{e}.pt"))
+    if rank == 0 and len(idx) > cut:
+        # one evaluation image, step by step (reference train.py:149-166): frames + GIF in output_dir
+        from .visualization import visualize_steps
+
+        pick = int(idx[cut + int(th.randint(0, len(idx) - cut, (1,)).item())])
+        x_u8 = dataset[pick][0]
+        visualize_steps(sampler, x_u8.to(device), x_u8, model_config.window_size, output_dir,
+                        dataset.class_to_idx)
     if distributed:
         dist.destroy_process_group()
     return trainer

@@ -50,3 +50,29 @@ def test_action_syntax_errors():
         parse_actions("[1,0],[0,1]", 2)
     with pytest.raises(AssertionError):
         parse_actions("[[1,0,0],[0,1,0]]", 2)
+
+
+def test_test_and_infer_flags_match_the_reference():
+    """reference __main__.py:217-300: the ``test`` and ``infer`` sub-commands and their flags."""
+    from marlclassification_amd.__main__ import build_parser
+
+    p = build_parser()
+    a = p.parse_args("--run-id r -a 5 --step 9 --cuda test --dataset-path d --json-path j "
+                     "--state-dict-path s -o out".split())
+    assert (a.main_choice, a.batch_size, a.img_size, a.dataset_path, a.output_dir) == ("test", 8, 28, "d", "out")
+    b = p.parse_args("--run-id r infer --images a.png b/*.png --json-path j --state-dict-path s "
+                     "--class2idx c.json -o out".split())
+    assert b.infer_images == ["a.png", "b/*.png"] and b.class_to_idx == "c.json" and b.output_image_dir == "out"
+
+
+def test_metric_formatting_and_confusion_png(tmp_path):
+    import torch as th
+
+    from marlclassification_amd.metrics import ConfusionMeter, format_metric
+
+    m = ConfusionMeter(3)
+    m.add(th.tensor([[0.9, 0.05, 0.05], [0.1, 0.8, 0.1], [0.2, 0.7, 0.1], [0.0, 0.1, 0.9]]), th.tensor([0, 1, 2, 2]))
+    assert m.conf_mat().tolist() == [[1, 0, 0], [0, 1, 0], [0, 1, 1]]
+    assert format_metric(m.recall(), {"a": 0, "b": 1, "c": 2}) == '"a" : 100.0%, "b" : 100.0%, "c" : 50.0%'
+    path = m.save_conf_matrix(3, str(tmp_path), "eval")
+    assert path.endswith("confusion_matrix_epoch_3_eval.png") and (tmp_path / "confusion_matrix_epoch_3_eval.png").exists()

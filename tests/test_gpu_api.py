@@ -206,3 +206,49 @@ def test_train_main_cli_end_to_end(device, tmp_path):
     assert all(bool(th.isfinite(v).all()) for v in sd.values())
     sd0 = th.load(out / "models" / "nn_models_epoch_0.pt", map_location="cpu")
     assert any(not th.equal(sd[k], sd0[k]) for k in sd), "weights did not change between epochs"
+
+
+def test_cli_train_test_infer_on_an_image_folder(device, tmp_path):
+    """the reference's three modes end to end on a (tiny) image-folder dataset
+    laid out like the reference's resources directory: ``train`` (dataset resolved under
+    ``downloaded/mnist_png/all_png``, per-epoch state dicts, confusion-matrix PNG, step GIF),
+    ``test`` (confusion matrix, precision / recall) and ``infer`` (frames + GIF per image)."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+
+    from marlclassification_amd.__main__ import main
+
+    res = tmp_path / "resources"
+    root = res / "downloaded" / "mnist_png" / "all_png"
+    rng = np.random.default_rng(0)
+    for c in range(3):
+        (root / f"class{c}").mkdir(parents=True)
+        for k in range(12):
+            arr = rng.integers(0, 256, (28, 28), dtype=np.uint8)
+            arr[4 * c: 4 * c + 8] = 255  # a class-dependent bright band
+            Image.fromarray(arr).save(root / f"class{c}" / f"img{k}.png")
+    out = tmp_path / "run"
+    common = "-a 3 --step 4 --cuda --run-id cli"
+    main((f"{common} train --ft-extr mnist --f 6 --img-size 28 --nb-class 3 --nb 32 --na 32 --nm 8 "
+          f"--nmo 12 --nd 8 --nlb 48 --nla 48 --batch-size 8 --nb-epoch 1 --lr 1e-3 --res-folder {res} "
+          f"-o {out}").split())
+    assert (out / "models" / "nn_models_epoch_0.pt").exists()
+    assert (out / "confusion_matrix_epoch_0_eval.png").exists()
+    assert (out / "animated_gif.gif").exists() and (out / "pred_step_3.png").exists()
+    assert json.loads((out / "class_to_idx.json").read_text()) == {"class0": 0, "class1": 1, "class2": 2}
+    # a wrong resources folder is an error, not a silent synthetic run (ADVICE r1)
+    with pytest.raises(NotADirectoryError):
+        main((f"{common} train --ft-extr mnist --f 6 --img-size 28 --nb-class 3 --res-folder {tmp_path / 'nope'} "
+              f"-o {out}").split())
+    test_out = tmp_path / "test_out"
+    main((f"{common} test --batch-size 8 --dataset-path {root} --img-size 28 --json-path {out / 'marl.json'} "
+          f"--state-dict-path {out / 'models' / 'nn_models_epoch_0.pt'} -o {test_out}").split())
+    assert (test_out / "confusion_matrix_epoch_0_test.png").exists()
+    inf_out = tmp_path / "infer_out"
+    main((f"{common} infer --images {root / 'class1' / 'img0.png'} {root / 'class2' / 'img*.png'} "
+          f"--json-path {out / 'marl.json'} --state-dict-path {out / 'models' / 'nn_models_epoch_0.pt'} "
+          f"--class2idx {out / 'class_to_idx.json'} -o {inf_out}").split())
+    assert (inf_out / "img0.png" / "animated_gif.gif").exists()
+    assert (inf_out / "img3.png" / "pred_step_0.png").exists() and (inf_out / "img3.png" / "info.txt").exists()
