@@ -1274,8 +1274,10 @@ static int cnn_dgrad_rb(CnnDgradArgs& a) {
     const int nt = (a.cin + 15) / 16;
     const int wpn = 8 / nt;
     if (wpn < 1) return 0;
-    for (int rb = 8; rb >= 1; --rb) {
-        if (cnn_dgrad_plan(a, rb) * sizeof(float) > 72 * 1024) continue;
+    const int rb_max = tune_get("dgrad_rb", 8);
+    const size_t lds_cap = (size_t)tune_get("dgrad_lds_kb", 72) * 1024;
+    for (int rb = rb_max < 8 ? (rb_max < 1 ? 1 : rb_max) : 8; rb >= 1; --rb) {
+        if (cnn_dgrad_plan(a, rb) * sizeof(float) > lds_cap) continue;
         if (a.MT > kDgradTiles * wpn || a.MT > 64) continue;
         if (rb > 1 && cdiv(a.rows, rb) < 512) continue;
         return rb;
