@@ -125,12 +125,58 @@ void prof_after(int cls, hipStream_t st);
 int profile_begin(int cls, int max_launches);
 int profile_end(double* total_ms, int* launches);
 
+struct RedQueue;
 // C[NI,NJ] = sum_r A[r,i] * B[r,j]  (weight gradients; contraction over rows).
 size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows);
 // colsum_out (nullable): also writes out[i] = sum_r A[r,i] (the matching bias gradient)
+// q != null: the slab reduction is queued there instead of launched (scratch comes from q too)
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
                    int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
-                   float* colsum_out = nullptr);
+                   float* colsum_out = nullptr, RedQueue* q = nullptr);
+
+// ---------------------------------------------------------------------------
+// Deferred fixed-order reductions (gemm.hip).  The backward pass produces ~40 sets of partial
+// sums (split-K slabs of the weight-gradient GEMMs, per-workgroup LayerNorm / GroupNorm affine
+// partials, conv weight-gradient slabs) whose results nobody reads before the end of the pass.
+// Instead of one or two tiny launches each (5-9 us + a kernel boundary apiece), they are queued
+// and reduced by ONE launch (two when a long reduction is folded in two stages).
+//   out[e] (+)= sum over z < count (fixed order) of part[z * stride + e],  e < n
+//   element e < split goes to out0[(e / nj) * ldc + e % nj], the others to out1[e - split]
+// ---------------------------------------------------------------------------
+struct RedDesc {
+    const float* part;
+    int64_t stride;
+    int count, n;
+    float* out0;
+    int split, nj, ldc;
+    float* out1;
+    int accumulate;
+    // folds > 1 (stage 1 of a long reduction): fold f sums the parts [f * per, (f + 1) * per)
+    // into out0[f * n + e]
+    int folds, per;
+};
+constexpr int kMaxRed = 40;
+struct RedBatch {
+    RedDesc d[kMaxRed];
+    int first_block[kMaxRed + 1];  // workgroups (fold, 64 elements) of descriptor i: [first_block[i], first_block[i + 1])
+    int count;
+};
+struct RedQueue {
+    RedBatch stage1, stage2;   // stage1: long reductions folded into temporaries first
+    float* scratch = nullptr;  // temporaries of stage 1 + bump space handed out by take()
+    size_t cap = 0, off = 0;
+    hipStream_t st = nullptr;
+    int rc = MARL_OK;
+    void reset(float* s, size_t floats, hipStream_t stream);
+    // scratch that stays valid until the next flush; when full: flushes (callers push what they
+    // took before they take again), or returns null if !may_flush
+    float* take(size_t floats, bool may_flush = true);
+    void push(const float* part, int64_t stride, int count, int n, float* out0, int split, int nj,
+              int ldc, float* out1, int accumulate);
+    int launch_pending();  // launch what is queued, keep the scratch handed out
+    int flush();           // + hand the scratch out anew
+};
+int launch_red_batch(const RedBatch& b, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // row-wise kernels (rowops.hip)
@@ -154,7 +200,7 @@ int launch_ln_silu_bwd(const float* da, int ldda, const float* z, int ldz, const
                        int64_t m, int n, hipStream_t st);
 // LayerNorm/GroupNorm partials [nparts][2][n] -> dgamma[n], dbeta[n]
 int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
-                         int accumulate, hipStream_t st);
+                         int accumulate, hipStream_t st, RedQueue* q = nullptr);
 
 // GroupNorm + SiLU over NHWC rows: z [rows, P, C] -> a.  out_chw != 0 writes element
 // (pos, c) at out[row * ldo + c * P + pos] (reference Flatten order), else NHWC with ldo = P*C.

@@ -243,6 +243,7 @@ struct ELayout {
         DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
     size_t PART, TNS, LOSS;
+    size_t RED, red_floats;  // scratch of the deferred-reduction queue (sum over every use)
     size_t part_floats, tns_bytes, loss_floats;
     size_t total;
     // which fused CNN kernels cover this shape (decides what is kept for backward)
@@ -396,14 +397,16 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
             e.DA[l] = (l + 1 < d.L && !e.dgrad_ok[l + 1]) ? b.take(NR * d.P[l] * d.ch[l + 1]) : 0;
         }
         // scratch sizes: maxima over every use
-        size_t part = 0, tns = 0;
+        size_t part = 0, tns = 0, red = 0;
         auto upd_part = [&](int64_t blocks, int n) {
             const size_t v = (size_t)blocks * 2 * n;
             part = v > part ? v : part;
+            red += ((v + 63) & ~(size_t)63) + 64 * 2 * (size_t)n + 64;  // + stage-1 temporaries
         };
         auto upd_tn = [&](int ni, int nj, int64_t rows) {
             const size_t v = gemm_tn_scratch_bytes(ni, nj, rows);
             tns = v > tns ? v : tns;
+            red += v / sizeof(float) + 64 * ((size_t)ni * nj + ni) + 192;
         };
         const int64_t nr = d.NR, r = d.R;
         upd_part(ln_bwd_blocks(nr, d.nlb), d.nlb);
@@ -434,6 +437,7 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
                 const size_t v = (size_t)cnn_wgrad_blocks(cnn_wgrad_shape(d, l)) *
                                  ((size_t)d.ch[l + 1] * d.K[l] + d.ch[l + 1]) * sizeof(float);
                 tns = v > tns ? v : tns;
+                red += v / sizeof(float) + 64 * ((size_t)d.ch[l + 1] * (d.K[l] + 1)) + 192;
             } else {
                 upd_tn(d.ch[l + 1], d.K[l], nr * d.P[l]);
             }
@@ -442,6 +446,12 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         e.tns_bytes = tns;
         e.PART = b.take(part);
         e.TNS = b.take(tns / sizeof(float) + 16);
+        {   // stage-1 temporaries of the four per-step LayerNorm reductions (their parts are PLN)
+            const int pn[4] = {d.n_mo, d.nm2, d.n_m, d.nm2};
+            for (int n : pn) red += 64 * 2 * (size_t)n + 64;
+        }
+        e.red_floats = red + 4096;
+        e.RED = b.take(e.red_floats);
     }
     e.loss_floats = loss_scratch_floats(d.ns, d.na, d.nb);
     e.LOSS = b.take(e.loss_floats);
@@ -459,6 +469,8 @@ struct Ctx {
     float* E;  // episode workspace
     hipStream_t st;
     int train;
+    RedQueue* rq = nullptr;  // backward: deferred reductions (null: every reduction launches at once)
+    bool defer_slabs = false;  // also the split-K / conv weight-gradient slabs (tens of MB each)
 
     const float* wp(int i) const { return W + w.wp[i]; }
     const float* wt(int i) const { return W + w.wt[i]; }
@@ -940,6 +952,9 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
             q.push(perm(c.gp(i), grads[i], m.n, m.k, m.k, 1, c.w.ldp[i], 0, 9, 1, ci));
         }
     }
+    // b_hh enters every gate sum exactly like b_ih: same gradient
+    q.push(perm(grads[MARL_P_LB_BIH], grads[MARL_P_LB_BHH], 1, 4 * c.d.n_b, 4 * c.d.n_b, 1, 0, 0, 1, 1, 0));
+    q.push(perm(grads[MARL_P_LA_BIH], grads[MARL_P_LA_BHH], 1, 4 * c.d.n_a, 4 * c.d.n_a, 1, 0, 0, 1, 1, 0));
     q.flush();
     return q.rc;
 }
@@ -951,7 +966,15 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
 static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, int pidx, int ni,
               int nj, int64_t rows, float* bias = nullptr) {
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
-                          c.e.tns_bytes, c.st, bias);
+                          c.e.tns_bytes, c.st, bias, c.defer_slabs ? c.rq : nullptr);
+}
+// scratch for `blocks` affine partial rows of width 2n: the queue's when the reduction can wait
+static float* part_scratch(const Ctx& c, int64_t blocks, int n, int acc, RedQueue*& q) {
+    q = acc ? nullptr : c.rq;
+    if (!q) return c.at(c.e.PART);
+    float* p = q->take((size_t)blocks * 2 * n);
+    if (q->rc != MARL_OK) q = nullptr;  // cannot happen with the layout's sizes; fall back
+    return q ? p : c.at(c.e.PART);
 }
 // LayerNorm+SiLU backward in place (da -> dz) with affine gradients (accumulated when acc)
 static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, const float* stats,
@@ -961,10 +984,11 @@ static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, co
         dz = da;
         lddz = ldda;
     }
-    MARL_TRY(launch_ln_silu_bwd(da, ldda, z, ldz, stats, c.wp(pw), c.wp(pb), dz, lddz,
-                                c.at(c.e.PART), rows, n, c.st));
-    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], acc,
-                                c.st);
+    RedQueue* q;
+    float* part = part_scratch(c, ln_bwd_blocks(rows, n), n, acc, q);
+    MARL_TRY(launch_ln_silu_bwd(da, ldda, z, ldz, stats, c.wp(pw), c.wp(pb), dz, lddz, part, rows, n,
+                                c.st));
+    return launch_reduce_affine(part, ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], acc, c.st, q);
 }
 
 // LayerNorm+SiLU backward of a hidden layer whose successor has only kin <= 4 outputs: the
@@ -972,14 +996,24 @@ static int ln_bwd(const Ctx& c, float* da, int ldda, const float* z, int ldz, co
 static int ln_bwd_rank(const Ctx& c, const float* g, int ldg, int kin, int w1, const float* z, int ldz,
                        const float* stats, int pw, int pb, int64_t rows, int n, float* const* grads,
                        float* dz, int lddz) {
+    RedQueue* q;
+    float* part = part_scratch(c, ln_bwd_blocks(rows, n), n, 0, q);
     MARL_TRY(launch_ln_silu_bwd_rank(g, ldg, kin, c.wt(w1), p4(kin), z, ldz, stats, c.wp(pw),
-                                     c.wp(pb), dz, lddz, c.at(c.e.PART), rows, n, c.st));
-    return launch_reduce_affine(c.at(c.e.PART), ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], 0,
-                                c.st);
+                                     c.wp(pb), dz, lddz, part, rows, n, c.st));
+    return launch_reduce_affine(part, ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], 0, c.st, q);
 }
 
-static int episode_backward(const Ctx& c, const void* img, int img_u8, const float* g_preds,
+static int episode_backward(const Ctx& c0, const void* img, int img_u8, const float* g_preds,
                             const float* g_logp, const float* g_values, float* const* grads) {
+    Ctx c = c0;
+    RedQueue rq;
+    rq.reset(c.at(c.e.RED), c.e.red_floats, c.st);
+    // 1: the small LayerNorm / GroupNorm affine partials wait for one launch at the end; the
+    // weight-gradient slabs (~0.4 GB per iteration in all) are reduced at once, while the
+    // Infinity Cache still holds them (2: defer those too - measured slower)
+    const int defer = tune_get("red_defer", 1);
+    if (defer) c.rq = &rq;
+    c.defer_slabs = defer > 1;
     const Dims& d = c.d;
     hipStream_t st = c.st;
     const int64_t NR = d.NR;
@@ -1051,6 +1085,9 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
     const size_t s_nmo = (size_t)d.R * d.ld_dbl, s_nm2 = (size_t)d.R * d.ld_nm2,
                  s_nm = (size_t)d.R * d.ld_nm;
     const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
+    // the per-step LayerNorm reductions of the unfused path accumulate into the gradients step
+    // by step: nothing of a parameter may still be queued then, so that path does not defer
+    if (!panels) c.rq = nullptr;
     // The action cell's backward of step t-1 only needs dh^_t, which is complete after step t's
     // W_hh product; it rides along (extra workgroups) with step t's decoder-panel launch, so
     // that from the second iteration on only the belief cell is left for the separate launch.
@@ -1206,14 +1243,14 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
     if (panels) {  // LayerNorm affine gradients of the in-loop layers: one reduction each
         const int64_t nblk = panel_bwd_blocks(R);
         MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[0]), nblk * ns, d.n_mo, grads[MARL_P_DEC_LN1W],
-                                      grads[MARL_P_DEC_LN1B], 0, st));
+                                      grads[MARL_P_DEC_LN1B], 0, st, c.rq));
         MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[1]), nblk * ns, d.nm2, grads[MARL_P_DEC_LN0W],
-                                      grads[MARL_P_DEC_LN0B], 0, st));
+                                      grads[MARL_P_DEC_LN0B], 0, st, c.rq));
         if (ns > 1) {
             MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[2]), nblk * (ns - 1), d.n_m,
-                                          grads[MARL_P_ENC_LN1W], grads[MARL_P_ENC_LN1B], 0, st));
+                                          grads[MARL_P_ENC_LN1W], grads[MARL_P_ENC_LN1B], 0, st, c.rq));
             MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[3]), nblk * (ns - 1), d.nm2,
-                                          grads[MARL_P_ENC_LN0W], grads[MARL_P_ENC_LN0B], 0, st));
+                                          grads[MARL_P_ENC_LN0W], grads[MARL_P_ENC_LN0B], 0, st, c.rq));
         }
     }
 
@@ -1233,10 +1270,8 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
     }
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.at(c.e.U, 0), d.ld_nin, MARL_P_LB_WIH, 4 * d.n_b, d.nin, NR));
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR, grads[MARL_P_LB_BIH]));
-    MARL_TRY(launch_copy2d(grads[MARL_P_LB_BIH], 0, grads[MARL_P_LB_BHH], 0, 1, 4 * d.n_b, st));
     MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.at(c.e.U, 0), d.ld_nin, MARL_P_LA_WIH, 4 * d.n_a, d.nin, NR));
     MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.HCs(0), d.ld_na, MARL_P_LA_WHH, 4 * d.n_a, d.n_a, NR, grads[MARL_P_LA_BIH]));
-    MARL_TRY(launch_copy2d(grads[MARL_P_LA_BIH], 0, grads[MARL_P_LA_BHH], 0, 1, 4 * d.n_a, st));
 
     // ---- dU for all steps, then position embedding and CNN backward -------------------
     {
@@ -1263,11 +1298,13 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
             const int64_t rows = NR * d.P[l];
             float* dz = c.at(c.e.DZ[l]);
             if (!have_dz) {
+                RedQueue* q;
+                float* part = part_scratch(c, gn_bwd_blocks(NR, co), co, 0, q);
                 MARL_TRY(launch_gn_silu_bwd(da, ldda, chw, c.at(c.e.Z[l], 0), c.at(c.e.GST[l], 0),
-                                            c.wp(4 * l + 2), c.wp(4 * l + 3), dz, c.at(c.e.PART), NR,
-                                            d.P[l], co, d.grp[l], st));
-                MARL_TRY(launch_reduce_affine(c.at(c.e.PART), gn_bwd_blocks(NR, co), co,
-                                              grads[4 * l + 2], grads[4 * l + 3], 0, st));
+                                            c.wp(4 * l + 2), c.wp(4 * l + 3), dz, part, NR, d.P[l], co,
+                                            d.grp[l], st));
+                MARL_TRY(launch_reduce_affine(part, gn_bwd_blocks(NR, co), co, grads[4 * l + 2],
+                                              grads[4 * l + 3], 0, st, q));
             }
             have_dz = false;
             if (c.e.wgrad_ok[l]) {
@@ -1287,10 +1324,21 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
                     set_error("episode_backward: the image batch of the forward call is needed");
                     return MARL_EINVAL;
                 }
-                w.part_w = c.at(c.e.TNS);  // the launcher places part_b behind the weight slabs
+                // per-workgroup slabs; the launcher places part_b behind the weight slabs
+                w.part_w = c.at(c.e.TNS);
+                if (c.rq && c.defer_slabs) {
+                    float* p = c.rq->take((size_t)cnn_wgrad_blocks(w) * ((size_t)co * d.K[l] + co));
+                    if (c.rq->rc == MARL_OK) w.part_w = p;
+                }
                 MARL_TRY(launch_cnn_wgrad(w, st));
-                MARL_TRY(launch_slab_reduce(w.part_w, (int64_t)co * d.K[l], w.blocks, c.gp(4 * l),
-                                            c.w.ldp[4 * l], co, d.K[l], w.part_b, grads[4 * l + 1], st));
+                if (c.rq && w.part_w != c.at(c.e.TNS)) {
+                    c.rq->push(w.part_w, (int64_t)co * d.K[l], w.blocks, co * d.K[l], c.gp(4 * l),
+                               co * d.K[l], d.K[l], c.w.ldp[4 * l], nullptr, 0);
+                    c.rq->push(w.part_b, co, w.blocks, co, grads[4 * l + 1], co, co, co, nullptr, 0);
+                } else {
+                    MARL_TRY(launch_slab_reduce(w.part_w, (int64_t)co * d.K[l], w.blocks, c.gp(4 * l),
+                                                c.w.ldp[4 * l], co, d.K[l], w.part_b, grads[4 * l + 1], st));
+                }
             } else {
                 MARL_TRY(tn(c, dz, co, c.at(c.e.COLS[l], 0), d.ldk[l], 4 * l, co, d.K[l], rows, grads[4 * l + 1]));
             }
@@ -1305,12 +1353,13 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
                 g.gamma = c.wp(4 * (l - 1) + 2);
                 g.beta = c.wp(4 * (l - 1) + 3);
                 g.dzin = c.at(c.e.DZ[l - 1]);
-                g.part = c.at(c.e.PART);
                 if (c.e.dgrad_ok[l] &&
                     (size_t)cnn_dgrad_blocks(g) * 2 * d.ch[l] <= c.e.part_floats) {
+                    RedQueue* q;
+                    g.part = part_scratch(c, cnn_dgrad_blocks(g), d.ch[l], 0, q);
                     MARL_TRY(launch_cnn_dgrad(g, st));
-                    MARL_TRY(launch_reduce_affine(c.at(c.e.PART), cnn_dgrad_blocks(g), d.ch[l],
-                                                  grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3], 0, st));
+                    MARL_TRY(launch_reduce_affine(g.part, cnn_dgrad_blocks(g), d.ch[l],
+                                                  grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3], 0, st, q));
                     have_dz = true;
                     continue;
                 }
@@ -1324,6 +1373,7 @@ static int episode_backward(const Ctx& c, const void* img, int img_u8, const flo
             }
         }
     }
+    MARL_TRY(rq.flush());
     return unpack_grads(c, grads);
 }
 

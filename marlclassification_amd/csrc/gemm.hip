@@ -568,6 +568,135 @@ int launch_slab_reduce(const float* part, int64_t stride, int splits, float* c, 
     return MARL_OK;
 }
 
+// Batched form of the same reduction: every 1024-thread workgroup owns 64 elements of ONE queued
+// descriptor (see RedQueue in common.h); 16 waves take the parts z = g, g + 16, ... with eight
+// loads in flight, the wave sums are added in wave order.
+__global__ __launch_bounds__(1024) void red_batch_kernel(const RedBatch B) {
+    __shared__ float sh[16][64];
+    __shared__ int sdesc;
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        int i = 0;
+        while (i + 1 < B.count && (int)blockIdx.x >= B.first_block[i + 1]) ++i;
+        sdesc = i;
+    }
+    __syncthreads();
+    const RedDesc D = B.d[sdesc];
+    const int nb = (D.n + 63) >> 6, local = (int)blockIdx.x - B.first_block[sdesc];
+    const int f = local / nb, e = (local - f * nb) * 64 + el;
+    const int z0 = f * D.per, zn = D.count - z0 < D.per ? D.count - z0 : D.per;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < D.n) {
+        const float* p = D.part + (size_t)z0 * D.stride + e;
+        int z = g;
+        for (; z + 112 < zn; z += 128) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + 16 * u) * D.stride];
+            s0 += v[0] + v[4];
+            s1 += v[1] + v[5];
+            s2 += v[2] + v[6];
+            s3 += v[3] + v[7];
+        }
+        for (; z < zn; z += 16) s0 += p[(size_t)z * D.stride];
+    }
+    sh[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < D.n) {
+        float t = sh[0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += sh[q][el];
+        float* o;
+        if (D.folds > 1) {
+            o = D.out0 + (size_t)f * D.n + e;
+        } else if (e < D.split) {
+            const int i = e / D.nj, j = e - i * D.nj;
+            o = D.out0 + (size_t)i * D.ldc + j;
+        } else {
+            o = D.out1 + (e - D.split);
+        }
+        if (D.accumulate) t += *o;
+        *o = t;
+    }
+}
+
+int launch_red_batch(const RedBatch& b, hipStream_t st) {
+    if (b.count <= 0) return MARL_OK;
+    hipLaunchKernelGGL(red_batch_kernel, dim3((unsigned)b.first_block[b.count]), dim3(1024), 0, st, b);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+void RedQueue::reset(float* s, size_t floats, hipStream_t stream) {
+    scratch = s;
+    cap = floats;
+    off = 0;
+    st = stream;
+    rc = MARL_OK;
+    stage1.count = stage2.count = 0;
+    stage1.first_block[0] = stage2.first_block[0] = 0;
+}
+
+float* RedQueue::take(size_t floats, bool may_flush) {
+    floats = (floats + 63) & ~(size_t)63;
+    if (off + floats > cap) {
+        if (!may_flush) return nullptr;
+        // everything handed out so far has been pushed: after the queued reductions (stream
+        // order) the space is free again
+        (void)flush();
+        if (floats > cap) {
+            rc = MARL_ESIZE;
+            set_error("reduction scratch too small (%zu > %zu floats)", floats, cap);
+            return scratch;
+        }
+    }
+    float* p = scratch + off;
+    off += floats;
+    return p;
+}
+
+static void red_add(RedBatch& b, const RedDesc& d) {
+    b.d[b.count] = d;
+    b.first_block[b.count + 1] = b.first_block[b.count] + d.folds * (int)cdiv(d.n, 64);
+    ++b.count;
+}
+
+void RedQueue::push(const float* part, int64_t stride, int count, int n, float* out0, int split, int nj,
+                    int ldc, float* out1, int accumulate) {
+    if (rc != MARL_OK || n <= 0 || count <= 0) return;
+    // long reductions: fold `count` parts into <= 64 temporaries first (stage 1), so that no
+    // thread walks more than a few dozen dependent loads
+    int folds = count > 1024 ? 64 : (count > 256 ? 16 : 1);
+    // (the scratch stays handed out here: `part` of this very call may live in it)
+    if (stage2.count + 1 > kMaxRed || stage1.count + (folds > 1) > kMaxRed) (void)launch_pending();
+    RedDesc d{part, stride, count, n, out0, split, nj, ldc, out1, accumulate, 1, count};
+    if (folds > 1) {
+        const int per = (int)cdiv(count, folds);
+        folds = (int)cdiv(count, per);
+        float* tmp = take((size_t)folds * n, false);
+        if (tmp) {  // (else: no room for the temporaries - one slow stage, still correct)
+            red_add(stage1, RedDesc{part, stride, count, n, tmp, n, n, n, nullptr, 0, folds, per});
+            d.part = tmp;
+            d.stride = n;
+            d.count = d.per = folds;
+        }
+    }
+    red_add(stage2, d);
+}
+
+int RedQueue::launch_pending() {
+    if (rc == MARL_OK && stage1.count) rc = launch_red_batch(stage1, st);
+    if (rc == MARL_OK && stage2.count) rc = launch_red_batch(stage2, st);
+    stage1.count = stage2.count = 0;
+    return rc;
+}
+
+int RedQueue::flush() {
+    (void)launch_pending();
+    off = 0;
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -801,7 +930,7 @@ size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows) {
 
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
                    int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
-                   float* colsum_out) {
+                   float* colsum_out, RedQueue* q) {
     if (!a || !b || !c || ni <= 0 || nj <= 0 || rows <= 0 || (lda & 3) || (ldb & 3) ||
         lda < p4(ni) || ldb < p4(nj) || (reinterpret_cast<uintptr_t>(a) & 15) ||
         (reinterpret_cast<uintptr_t>(b) & 15)) {
@@ -813,6 +942,11 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     float* out = c;
     int ldo = ldc;
     int64_t stride = 0;
+    if (p.splits > 1 && q) {  // partial slabs live in the queue's scratch until its flush
+        scratch = q->take(gemm_tn_scratch_bytes(ni, nj, rows) / sizeof(float));
+        scratch_bytes = gemm_tn_scratch_bytes(ni, nj, rows);
+        if (q->rc != MARL_OK) return q->rc;
+    }
     if (p.splits > 1) {
         if (!scratch || scratch_bytes < gemm_tn_scratch_bytes(ni, nj, rows)) {
             set_error("gemm_tn: scratch too small");
@@ -856,6 +990,11 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
 #undef MARL_TN_LAUNCH
     prof_after(2, st);
     MARL_LAUNCH_CHECK();
+    if (p.splits > 1 && q) {
+        q->push(scratch, stride, p.splits, ni * nj, c, ni * nj, nj, ldc, nullptr, 0);
+        if (colsum_out) q->push(csum, ni, p.splits, ni, colsum_out, ni, ni, ni, nullptr, 0);
+        return q->rc;
+    }
     if (p.splits > 1)
         MARL_TRY(launch_slab_reduce(scratch, stride, p.splits, c, ldc, ni, nj,
                                     colsum_out ? csum : nullptr, colsum_out, st));

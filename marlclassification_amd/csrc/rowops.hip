@@ -462,8 +462,12 @@ __global__ __launch_bounds__(256) void reduce_affine_kernel(const float* __restr
 // NOTE: long reductions (>= 256 parts) fold the partial buffer in place first - `part` is
 // consumed by this call.
 int launch_reduce_affine(float* part, int64_t nparts, int n, float* dgamma, float* dbeta,
-                         int accumulate, hipStream_t st) {
+                         int accumulate, hipStream_t st, RedQueue* q) {
     if (n <= 0) return MARL_OK;
+    if (q && !accumulate) {  // queued: `part` must stay untouched until the queue is flushed
+        q->push(part, (int64_t)2 * n, (int)nparts, 2 * n, dgamma, n, n, n, dbeta, 0);
+        return q->rc;
+    }
     int64_t pstep = 1;
     if (nparts >= 256) {
         int chunk = 16;
