@@ -344,13 +344,21 @@ struct PanelLayer {
     float* a;      // SiLU(LN(z)) [M, lda]
     int lda;
 };
+constexpr int kPanelMaxLayers = 4;
 struct PanelFwdProb {
     const float* x;  // [M, ldx] input rows, or the message tensor when agg_na > 0
     int ldx, k0;
     int agg_na, agg_nb;  // message mean over the other agents computed while staging
-    float* xbar;         // [M, ldx] receives the staged input in agg mode (nullable)
+    float* xbar;         // [M, ldx'] receives the aggregated rows (staging or agg_at; nullable)
     int m, nlayers;
-    PanelLayer layer[2];
+    PanelLayer layer[kPanelMaxLayers];
+    // by_batch > 0: a workgroup owns ALL agents of by_batch consecutive batch elements (local row
+    // lr = a * by_batch + i is global row a * g_nb + blockIdx.x * by_batch + i) instead of
+    // kPanelRows consecutive rows, so that the message mean over the other agents
+    // (networks/message.py:5-17) can be taken inside the workgroup: agg_at = l > 0 applies it to
+    // layer l's input panel in LDS (encoder -> mean -> decoder in ONE launch) and stores the
+    // aggregated rows to xbar [M, ld_xbar].
+    int by_batch, g_na, g_nb, agg_at, ld_xbar;
 };
 struct PanelFwdBatch {
     PanelFwdProb p[2];
@@ -364,6 +372,8 @@ struct PanelFwdBatch {
     long long* ts;  // phase timestamps of one workgroup (debug builds only)
 #endif
 };
+// the encoder -> mean -> decoder chain in one workgroup: all agents of a batch element fit a panel
+int panel_chain_supported(int na, int n_msg, int threads);
 int panel_supported(int k0, int n0, int n1);
 int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st);
 
@@ -382,15 +392,20 @@ struct LstmBwdBatch {
     LstmBwdArgs a[2];
     int64_t rows;
 };
+// element (r, u) with dL/dh given
+__device__ __forceinline__ void lstm_cell_bwd_at(const LstmBwdArgs& A, int64_t r, int u, float dhv);
 __device__ __forceinline__ void lstm_cell_bwd_elem(const LstmBwdArgs& A, int64_t rows, int64_t idx) {
     const int n = A.n;
     if (idx >= rows * n) return;
     const int64_t r = idx / n;
     const int u = (int)(idx % n);
+    lstm_cell_bwd_at(A, r, u, A.dh[r * A.lddh + u]);
+}
+__device__ __forceinline__ void lstm_cell_bwd_at(const LstmBwdArgs& A, int64_t r, int u, float dhv) {
+    const int n = A.n;
     float* g = A.gates + r * A.ldg + u;
     const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
     const float tc = tanhf(A.c_new[r * A.ldc + u]);
-    const float dhv = A.dh[r * A.lddh + u];
     const float dcv = dhv * go * (1.0f - tc * tc) + A.dc[r * A.lddc + u];
     g[0] = dcv * gg * gi * (1.0f - gi);
     g[n] = dcv * A.c_prev[r * A.ldc + u] * gf * (1.0f - gf);
@@ -423,10 +438,18 @@ struct PanelBwdProb {
     // (self-adjoint, networks/message.py:5-17) is applied while staging (rows are a * agg_nb + b)
     int agg_na, agg_nb;
     int m, nlayers;
-    PanelBwdLayer layer[2];
+    PanelBwdLayer layer[kPanelMaxLayers];
     float* dx;  // out: d loss / d (input of the first layer) [M, lddx]
     int lddx, accumulate;
-    int off_e, off_prm, off_colp, off_part;  // LDS float offsets (filled by the launcher)
+    // by_batch > 0: a workgroup owns all agents of by_batch batch elements (see PanelFwdProb), and
+    // agg_at = l > 0 applies the (self-adjoint) message mean to the gradient panel entering layer
+    // l: decoder backward -> mean -> encoder backward of the previous step in ONE launch
+    int by_batch, g_na, g_nb, agg_at;
+    // has_cellb: the rows of dx are complete after this kernel's update (dx = dL/dh of the belief
+    // cell): its elementwise backward runs in the epilogue, on the value still in registers
+    int has_cellb;
+    LstmBwdArgs cellb;
+    int off_e, off_prm, off_colp, off_part, off_rowmap;  // LDS float offsets (filled by the launcher)
     // optional: extra workgroups behind the panel ones run one LSTM cell's elementwise backward
     // (an independent memory-bound kernel riding along with this latency-bound one)
     int has_cell, panel_blocks;
@@ -434,6 +457,7 @@ struct PanelBwdProb {
     int64_t cell_rows;
 };
 int panel_bwd_blocks(int m);
+int panel_chain_blocks(int na, int nb);  // workgroups of a by_batch launch
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------

@@ -384,7 +384,9 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         int maxg = 4 * (d.n_b > d.n_a ? d.n_b : d.n_a);
         e.BTMP = b.take((size_t)maxg);
         {   // per-step LayerNorm affine partials of the panel backward kernels
-            const size_t nblk = (size_t)panel_bwd_blocks((int)d.R) * d.ns * 2;
+            int blocks = panel_bwd_blocks((int)d.R);
+            if (panel_chain_blocks(d.na, d.nb) > blocks) blocks = panel_chain_blocks(d.na, d.nb);
+            const size_t nblk = (size_t)blocks * d.ns * 2;
             e.PLN[0] = b.take(nblk * d.n_mo);  // decode LN1
             e.PLN[1] = b.take(nblk * d.nm2);   // decode LN0
             e.PLN[2] = b.take(nblk * d.n_m);   // encode LN1
@@ -607,6 +609,20 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
     return MARL_OK;
 }
 
+// the decoder's two layers of step t (outputs: AD1[t], U[t][:, nf:nf+n_mo])
+static void fill_dec_layers(const Ctx& c, int t, PanelLayer* layer) {
+    const Dims& d = c.d;
+    const bool keep = c.train != 0;
+    layer[0] = PanelLayer{c.wp(MARL_P_DEC_W0), p4(d.n_m), c.wp(MARL_P_DEC_B0),
+                          c.wp(MARL_P_DEC_LN0W), c.wp(MARL_P_DEC_LN0B), d.nm2,
+                          keep ? c.at(c.e.ZD1, t) : nullptr, d.ld_nm2,
+                          keep ? c.at(c.e.STD1, t) : nullptr, c.at(c.e.AD1, t), d.ld_nm2};
+    layer[1] = PanelLayer{c.wp(MARL_P_DEC_W1), d.ld_nm2, c.wp(MARL_P_DEC_B1),
+                          c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo,
+                          keep ? c.at(c.e.ZD2, t) : nullptr, d.ld_nmo,
+                          keep ? c.at(c.e.STD2, t) : nullptr, c.at(c.e.U, t) + d.nf, d.ld_nin};
+}
+
 // message mean over the other agents + decoder -> U[t][:, nf:nf+n_mo]   (needs MSG[t])
 // `sample` (panel path only): the sampling rows of the PREVIOUS step ride along in the same
 // launch (they are independent of the decoder); *fused reports whether that happened
@@ -614,7 +630,6 @@ static int step_decode(const Ctx& c, int t, const SampleArgs* sample = nullptr, 
     const Dims& d = c.d;
     const int R = (int)d.R;
     hipStream_t st = c.st;
-    const bool keep = c.train != 0;
     if (use_panels(d)) {
         PanelFwdBatch pb{};
         pb.count = 1;
@@ -627,14 +642,7 @@ static int step_decode(const Ctx& c, int t, const SampleArgs* sample = nullptr, 
         p.xbar = c.at(c.e.MBAR, t);
         p.m = R;
         p.nlayers = 2;
-        p.layer[0] = PanelLayer{c.wp(MARL_P_DEC_W0), p4(d.n_m), c.wp(MARL_P_DEC_B0),
-                                c.wp(MARL_P_DEC_LN0W), c.wp(MARL_P_DEC_LN0B), d.nm2,
-                                keep ? c.at(c.e.ZD1, t) : nullptr, d.ld_nm2,
-                                keep ? c.at(c.e.STD1, t) : nullptr, c.at(c.e.AD1, t), d.ld_nm2};
-        p.layer[1] = PanelLayer{c.wp(MARL_P_DEC_W1), d.ld_nm2, c.wp(MARL_P_DEC_B1),
-                                c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo,
-                                keep ? c.at(c.e.ZD2, t) : nullptr, d.ld_nmo,
-                                keep ? c.at(c.e.STD2, t) : nullptr, c.at(c.e.U, t) + d.nf, d.ld_nin};
+        fill_dec_layers(c, t, p.layer);
         if (sample) {
             pb.has_sample = 1;
             pb.sample = *sample;
@@ -763,6 +771,34 @@ static int step_encode_policy(const Ctx& c, int t, int which) {
                                     c.at(c.e.STE2, t), d.R, d.n_m, st));
     }
     return MARL_OK;
+}
+
+// All agents of a batch element in one workgroup (rows a * nb + b for every a), so that the
+// message mean over the other agents needs no second launch:
+//   forward : encoder(t) -> MSG[t+1] -> mean -> decoder(t+1) -> U[t+1]  ||  policy hidden layer(t)
+//   backward: decoder(t) -> mean -> encoder(t-1) -> dh_t complete -> belief cell(t-1)
+static bool use_chain(const Dims& d) {
+    return use_panels(d) && panel_chain_supported(d.na, d.n_m, 256) && d.n_mo <= 384 && d.nm2 <= 384 &&
+           d.n_m <= 384 && tune_get("panel_chain", 1) != 0;
+}
+static int step_chain(const Ctx& c, int t) {
+    const Dims& d = c.d;
+    PanelFwdBatch pb{};
+    pb.count = 2;
+    PanelFwdProb& pe = pb.p[0];
+    fill_enc_prob(c, t, pe);
+    pe.by_batch = 16 / d.na;
+    pe.g_na = d.na;
+    pe.g_nb = d.nb;
+    if (t + 1 < d.ns) {
+        fill_dec_layers(c, t + 1, pe.layer + 2);
+        pe.nlayers = 4;
+        pe.agg_at = 2;
+        pe.xbar = c.at(c.e.MBAR, t + 1);
+        pe.ld_xbar = d.ld_nm;
+    }
+    fill_pol_prob(c, t, pb.p[1]);
+    return launch_panel_fwd(pb, c.st);
 }
 
 // whole step on one stream (standalone step API)
@@ -1094,9 +1130,14 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     const bool ride = panels && !use_side_stream();
     const bool dl_in_loop = ride;  // dU[:, nf:] (message + embedding columns) comes out of the loop
     bool action_done = false;  // the action cell of this step was handled by the ride-along
+    bool belief_done = false;  // the belief cell: by the epilogue of the chained panel launch
+    const bool chain = ride && use_chain(d);
+    const int pln_blocks = chain ? panel_chain_blocks(d.na, d.nb) : panel_bwd_blocks(R);
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
-        if (action_done)
+        if (action_done && belief_done) {
+            // both cells of this step were handled inside the previous iteration's panel launch
+        } else if (action_done)
             MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
                                           d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.R, d.n_b, st));
         else
@@ -1105,7 +1146,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                                            d.n_b, c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
                                            c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1),
                                            d.ld_na, d.n_a, d.R, st));
-        action_done = false;
+        action_done = belief_done = false;
         // The W_hh recurrent GEMM (main stream) and the decoder / encoder backward chain (side
         // stream) only meet at DH[t]: the chain's last kernel waits for the GEMM.
         const bool side = panels && use_side_stream();
@@ -1157,7 +1198,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         }
         float* dad1 = c.at(c.e.DAD1) + (size_t)t * s_nm2;
         if (panels) {
-            const size_t pblk = (size_t)panel_bwd_blocks(R) * 2;
+            const size_t pblk = (size_t)pln_blocks * 2;
             PanelBwdProb pd{};
             pd.da = ddbar;
             pd.ldda = d.ld_dbl;
@@ -1184,6 +1225,35 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                                       c.CCs(t), d.ld_na, d.ld_na, d.ld_ga, d.ld_na, d.n_a};
                 pd.cell_rows = d.R;
                 action_done = true;
+            }
+            if (chain) {
+                // decoder(t) -> mean -> encoder(t-1) -> dh_t -> belief cell(t-1), one launch
+                pd.by_batch = 16 / d.na;
+                pd.g_na = d.na;
+                pd.g_nb = d.nb;
+                if (t > 0) {
+                    pd.nlayers = 4;
+                    pd.agg_at = 2;
+                    pd.layer[2] = PanelBwdLayer{c.at(c.e.ZE2, t - 1), d.ld_nm, c.at(c.e.STE2, t - 1),
+                                                c.wp(MARL_P_ENC_LN1W), c.wp(MARL_P_ENC_LN1B), d.n_m,
+                                                c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm, d.ld_nm,
+                                                c.at(c.e.PLN[2]) + (size_t)(t - 1) * pblk * d.n_m,
+                                                c.wt(MARL_P_ENC_W1), p4(d.n_m), d.nm2};
+                    pd.layer[3] = PanelBwdLayer{c.at(c.e.ZE1, t - 1), d.ld_nm2, c.at(c.e.STE1, t - 1),
+                                                c.wp(MARL_P_ENC_LN0W), c.wp(MARL_P_ENC_LN0B), d.nm2,
+                                                c.at(c.e.DAE1) + (size_t)(t - 1) * s_nm2, d.ld_nm2,
+                                                c.at(c.e.PLN[3]) + (size_t)(t - 1) * pblk * d.nm2,
+                                                c.wt(MARL_P_ENC_W0), p4(d.nm2), d.n_b};
+                    pd.dx = c.DHs(t);
+                    pd.lddx = d.ld_nb;
+                    pd.accumulate = 1;
+                    pd.has_cellb = 1;
+                    pd.cellb = LstmBwdArgs{c.DHs(t), c.at(c.e.DC), c.at(c.e.GB, t - 1), c.Cs(t - 1), c.Cs(t),
+                                           d.ld_nb, d.ld_nb, d.ld_gb, d.ld_nb, d.n_b};
+                    belief_done = true;
+                }
+                MARL_TRY(launch_panel_bwd(pd, st));
+                continue;
             }
             MARL_TRY(launch_panel_bwd(pd, st));
             if (t > 0) {
@@ -1241,7 +1311,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         }
     }
     if (panels) {  // LayerNorm affine gradients of the in-loop layers: one reduction each
-        const int64_t nblk = panel_bwd_blocks(R);
+        const int64_t nblk = pln_blocks;
         MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[0]), nblk * ns, d.n_mo, grads[MARL_P_DEC_LN1W],
                                       grads[MARL_P_DEC_LN1B], 0, st, c.rq));
         MARL_TRY(launch_reduce_affine(c.at(c.e.PLN[1]), nblk * ns, d.nm2, grads[MARL_P_DEC_LN0W],
@@ -1504,6 +1574,7 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         c2.st = g_side.s;
     }
     bool decoded_ahead = false;  // decoder(t) already ran with the sampling of step t-1
+    const bool chain = !side && use_chain(d);
     for (int t = 0; t < d.ns; ++t) {
         MARL_TRY(step_cnn(c, t, in));
         if (side && t > 0)
@@ -1511,7 +1582,9 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         else if (!decoded_ahead)
             MARL_TRY(step_decode(c, t));
         MARL_TRY(step_pos_lstm(c, t, in, t > 0));  // lambda_t (t > 0) came from sample(t-1)
-        if (side) {
+        if (chain) {
+            MARL_TRY(step_chain(c, t));  // encoder(t) -> decoder(t+1) || policy layer(t)
+        } else if (side) {
             MARL_TRY(g_side.order(c.st, c2.st));  // side stream: after the LSTM of step t
             MARL_TRY(step_encode_policy(c2, t, 1));
             if (t + 1 < d.ns) MARL_TRY(step_decode(c2, t + 1));
@@ -1545,9 +1618,9 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
         }
         // sample(t) and decoder(t+1) are independent (the decoder needs MSG[t+1], written by the
         // encoder above): one launch runs both
-        decoded_ahead = false;
-        if (!side && t + 1 < d.ns) MARL_TRY(step_decode(c, t + 1, &a, &decoded_ahead));
-        if (!decoded_ahead) MARL_TRY(launch_sample(a, c.st));
+        decoded_ahead = chain && t + 1 < d.ns;
+        if (!side && !chain && t + 1 < d.ns) MARL_TRY(step_decode(c, t + 1, &a, &decoded_ahead));
+        if (chain || !decoded_ahead) MARL_TRY(launch_sample(a, c.st));
     }
     if (side) MARL_TRY(g_side.order(c2.st, c.st));  // join before the caller's stream continues
     return heads_batched(c, 0, d.NR, step_values, step_preds);

@@ -139,8 +139,20 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
     }
     const PanelFwdProb& P = B.p[blockIdx.y];
     const int m0 = blockIdx.x * kPanelRows;
-    if (m0 >= P.m) return;
+    const int bpb = P.by_batch;  // > 0: this workgroup owns all agents of bpb batch elements
+    if (bpb ? (int)blockIdx.x * bpb >= P.g_nb : m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    // global row of local row lr, or -1 (padding): a small table in LDS
+    int* rowmap = reinterpret_cast<int*>(lds + B.off_red);
+    if (tid < kPanelRows) {
+        int r = m0 + tid < P.m ? m0 + tid : -1;
+        if (bpb) {
+            const int a = tid / bpb, b = (int)blockIdx.x * bpb + (tid - a * bpb);
+            r = (a < P.g_na && b < P.g_nb) ? a * P.g_nb + b : -1;
+        }
+        rowmap[tid] = r;
+    }
+    lds_barrier();
     const int quad = lane >> 4, l16 = lane & 15;
 #ifdef MARL_KERNEL_TS
     MARL_TS_DECL(B.ts);
@@ -174,9 +186,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
             const float den = (float)(na - 1);
             for (int e = tid; e < kPanelRows * c4; e += blockDim.x) {
                 const int lr = e / c4, k = (e % c4) * 4;
-                const int r = m0 + lr;
+                const int r = rowmap[lr];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < P.m && k < K4 && na > 1) {
+                if (r >= 0 && k < K4 && na > 1) {
                     const int b = r % nb;
                     const float* base = P.x + (size_t)b * P.ldx + k;
                     const size_t astr = (size_t)nb * P.ldx;
@@ -209,9 +221,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         } else {
             for (int e = tid; e < kPanelRows * c4; e += blockDim.x) {
                 const int lr = e / c4, k = (e % c4) * 4;
-                const int r = m0 + lr;
+                const int r = rowmap[lr];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < P.m && k < K4) v = *reinterpret_cast<const float4*>(P.x + (size_t)r * P.ldx + k);
+                if (r >= 0 && k < K4) v = *reinterpret_cast<const float4*>(P.x + (size_t)r * P.ldx + k);
                 *reinterpret_cast<float4*>(X + lr * xs + k) = v;
             }
         }
@@ -220,16 +232,60 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
     lds_barrier();
     MARL_TS();
 
+    int prm_off = 0, K = P.k0;
     for (int l = 0; l < P.nlayers; ++l) {
         const PanelLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
-        const float* lbias = prm + (l == 0 ? 0 : 3 * P.layer[0].n);
+        const float* lbias = prm + prm_off;
         const float* lgamma = lbias + Lr.n;
         const float* lbeta = lgamma + Lr.n;
-        const float* in = (l & 1) ? Y : X;
+        prm_off += 3 * Lr.n;
+        float* in = (l & 1) ? Y : X;
         float* outp = (l & 1) ? X : Y;  // this layer's output panel (next layer's input)
-        const int K = l == 0 ? P.k0 : P.layer[0].n;
         const int K16 = (K + 15) & ~15;
         const int stride = panel_stride(K);
+        if (l > 0 && l == P.agg_at) {
+            // the panel holds the messages of every agent of this workgroup's batch elements:
+            // message mean over the OTHER agents in place (sequential over agents, as the
+            // reference's sum(dim=0)), kept in xbar for the weight gradients
+            const int c4 = K16 >> 2, K4 = (K + 3) & ~3, na = P.g_na;
+            const float den = (float)(na - 1);
+            float4 v[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {  // launcher: kPanelRows * c4 <= 2 * blockDim.x
+                const int e = tid + it * (int)blockDim.x;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e - lr * c4) * 4;
+                    const int a = lr / bpb, i = lr - a * bpb;
+                    if (a < na && na > 1) {
+                        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int a2 = 0; a2 < na; ++a2) {
+                            const float4 q = *reinterpret_cast<const float4*>(in + (a2 * bpb + i) * stride + k);
+                            sm.x += q.x;
+                            sm.y += q.y;
+                            sm.z += q.z;
+                            sm.w += q.w;
+                        }
+                        const float4 me = *reinterpret_cast<const float4*>(in + lr * stride + k);
+                        v[it] = make_float4((sm.x - me.x) / den, (sm.y - me.y) / den, (sm.z - me.z) / den,
+                                            (sm.w - me.w) / den);
+                    }
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * (int)blockDim.x;
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e - lr * c4) * 4;
+                    *reinterpret_cast<float4*>(in + lr * stride + k) = v[it];
+                    const int r = rowmap[lr];
+                    if (r >= 0 && k < K4 && P.xbar)
+                        *reinterpret_cast<float4*>(P.xbar + (size_t)r * P.ld_xbar + k) = v[it];
+                }
+            }
+            lds_barrier();
+        }
         const int n = Lr.n, nt = (n + 31) >> 5;
         const int ks = panel_ksplit(K, nt, nwaves);
         const int j = wave % nt, s = wave / nt;
@@ -246,6 +302,9 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         // z = acc + bias -> output panel in LDS (and global, kept for backward)
         const int ys = panel_stride(n), n16 = (n + 15) & ~15;
         if (active && s == 0) {
+            int rw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rw[r] = Lr.z ? rowmap[4 * quad + r] : -1;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = j * 32 + 16 * t + l16;
@@ -256,7 +315,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                     const int lr = 4 * quad + r;
                     const float zv = cv ? acc[t][r] + bv : 0.f;
                     if (col < n16) outp[lr * ys + col] = zv;
-                    if (cv && Lr.z && m0 + lr < P.m) Lr.z[(size_t)(m0 + lr) * Lr.ldz + col] = zv;
+                    if (cv && rw[r] >= 0) Lr.z[(size_t)rw[r] * Lr.ldz + col] = zv;
                 }
             }
         }
@@ -299,18 +358,18 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                         q += d * d;
                     }
                     const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + 1e-5f);
-                    const int row = m0 + lr;
-                    float* arow = Lr.a + (size_t)row * Lr.lda;
+                    const int row = rowmap[lr];
+                    float* arow = Lr.a + (size_t)(row < 0 ? 0 : row) * Lr.lda;
 #pragma unroll
                     for (int u = 0; u < kPanelMaxCols; ++u) {
                         const int c = lane + 64 * u;
                         if (c < n) {
                             const float av = silu_p(v[u] * rstd * g[u] + bt[u]);
                             zr[c] = av;
-                            if (row < P.m) arow[c] = av;
+                            if (row >= 0) arow[c] = av;
                         }
                     }
-                    if (Lr.stats && lane == 0 && row < P.m) {
+                    if (Lr.stats && lane == 0 && row >= 0) {
                         Lr.stats[(size_t)row * 2] = mean;
                         Lr.stats[(size_t)row * 2 + 1] = rstd;
                     }
@@ -320,6 +379,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         MARL_TS();
         lds_barrier();
         MARL_TS();
+        K = n;
     }
 }
 
@@ -333,6 +393,11 @@ static int panel_waves_for(int k, int n) {
     return w > kPanelMaxWaves ? (nt > kPanelMaxWaves ? -1 : (kPanelMaxWaves / nt) * nt) : w;
 }
 
+int panel_chain_supported(int na, int n_msg, int threads) {
+    const int K16 = (n_msg + 15) & ~15;  // (two passes of the workgroup cover the message panel)
+    return na >= 1 && na <= kPanelRows && kPanelRows * (K16 / 4) <= 2 * threads;
+}
+
 int panel_supported(int k0, int n0, int n1) {
     if (n0 > 32 * kPanelMaxWaves || n1 > 32 * kPanelMaxWaves) return 0;  // one column tile per wave
     if (n0 > 64 * kPanelMaxCols || n1 > 64 * kPanelMaxCols) return 0;
@@ -344,22 +409,31 @@ int panel_supported(int k0, int n0, int n1) {
 }
 
 int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
-    int mmax = 0, waves = 1, x0 = 0, x1 = 0;
+    int waves = 1, x0 = 0, x1 = 0;
     for (int i = 0; i < b.count; ++i) {
         const PanelFwdProb& p = b.p[i];
-        mmax = p.m > mmax ? p.m : mmax;
         for (int l = 0; l < p.nlayers; ++l) {
-            const int w = panel_waves_for(l == 0 ? p.k0 : p.layer[0].n, p.layer[l].n);
+            const int w = panel_waves_for(l == 0 ? p.k0 : p.layer[l - 1].n, p.layer[l].n);
             if (w < 0) {
                 set_error("panel kernel: layer width %d too large", p.layer[l].n);
                 return MARL_ELIMIT;
             }
             waves = w > waves ? w : waves;
         }
-        int s0 = kPanelRows * panel_stride(p.k0);
-        if (p.nlayers > 1 && kPanelRows * panel_stride(p.layer[1].n) > s0)
-            s0 = kPanelRows * panel_stride(p.layer[1].n);  // layer 1 writes its output panel here
-        const int s1 = kPanelRows * panel_stride(p.layer[0].n);
+        // X: the input and the outputs of the odd layers; Y: the outputs of the even layers
+        int s0 = kPanelRows * panel_stride(p.k0), s1 = 0;
+        for (int l = 0; l < p.nlayers; ++l) {
+            const int v = kPanelRows * panel_stride(p.layer[l].n);
+            if (l & 1)
+                s0 = v > s0 ? v : s0;
+            else
+                s1 = v > s1 ? v : s1;
+        }
+        if (p.agg_at > 0 && (p.by_batch < 1 || p.g_na * p.by_batch > kPanelRows || p.agg_at >= p.nlayers ||
+                             !panel_chain_supported(p.g_na, p.layer[p.agg_at - 1].n, 256))) {
+            set_error("panel kernel: in-panel message mean outside its range");
+            return MARL_ELIMIT;
+        }
         x0 = s0 > x0 ? s0 : x0;
         x1 = s1 > x1 ? s1 : x1;
     }
@@ -389,7 +463,12 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
                                            (int)kPanelMaxLds));
         raised = true;
     }
-    const unsigned pblocks = (unsigned)cdiv(mmax, kPanelRows);
+    unsigned pblocks = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const PanelFwdProb& p = b.p[i];
+        const unsigned nblk = p.by_batch > 0 ? (unsigned)cdiv(p.g_nb, p.by_batch) : (unsigned)cdiv(p.m, kPanelRows);
+        pblocks = nblk > pblocks ? nblk : pblocks;
+    }
 #ifdef MARL_KERNEL_TS
     static long long* d_ts = nullptr;
     static int calls = 0;
@@ -432,7 +511,8 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
         return;
     }
     const int m0 = blockIdx.x * kPanelRows;
-    if (m0 >= P.m) return;
+    const int bpb = P.by_batch;  // > 0: this workgroup owns all agents of bpb batch elements
+    if (bpb ? (int)blockIdx.x * bpb >= P.g_nb : m0 >= P.m) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int quad = lane >> 4, l16 = lane & 15;
     float* D = lds;            // current gradient panel
@@ -440,6 +520,17 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
     float* prm = lds + P.off_prm;
     float* colp = lds + P.off_colp;  // [nwaves][2][n]
     float* part = lds + P.off_part;
+    // global row of local row lr, or -1 (padding): a small table in LDS
+    int* rowmap = reinterpret_cast<int*>(lds + P.off_rowmap);
+    if (tid < kPanelRows) {
+        int r = m0 + tid < P.m ? m0 + tid : -1;
+        if (bpb) {
+            const int a = tid / bpb, b = (int)blockIdx.x * bpb + (tid - a * bpb);
+            r = (a < P.g_na && b < P.g_nb) ? a * P.g_nb + b : -1;
+        }
+        rowmap[tid] = r;
+    }
+    lds_barrier();
 
     // LayerNorm affine parameters of every layer -> LDS; d(a_last) panel -> D
     {
@@ -456,9 +547,9 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
         const int n4 = (n + 3) & ~3;
         for (int e = tid; e < kPanelRows * c4; e += blockDim.x) {
             const int lr = e / c4, k = (e % c4) * 4;
-            const int r = m0 + lr;
+            const int r = rowmap[lr];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < P.m && k < n4 && P.agg_na > 1) {
+            if (r >= 0 && k < n4 && P.agg_na > 1) {
                 const int na = P.agg_na, nb = P.agg_nb;
                 const float den = (float)(na - 1);
                 const float* base = P.da + (size_t)(r % nb) * P.ldda + k;
@@ -484,7 +575,7 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
                 const float4 me = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
                 v = make_float4((s.x - me.x) / den, (s.y - me.y) / den, (s.z - me.z) / den,
                                 (s.w - me.w) / den);
-            } else if (r < P.m && k < n4 && P.agg_na == 0) {
+            } else if (r >= 0 && k < n4 && P.agg_na == 0) {
                 v = *reinterpret_cast<const float4*>(P.da + (size_t)r * P.ldda + k);
                 if (P.da2) {
                     const float4 w = *reinterpret_cast<const float4*>(P.da2 + (size_t)r * P.ldda2 + k);
@@ -503,6 +594,46 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
         const float* lgamma = prm + prm_off;
         const float* lbeta = lgamma + n;
         prm_off += 2 * n;
+        if (l > 0 && l == P.agg_at) {
+            // D holds the gradient of the message MEAN for every agent of this workgroup's batch
+            // elements: the mean over the other agents is self-adjoint - the same sum (sequential
+            // over agents, as the staging version) gives the gradient of the messages
+            const int c4 = n16 >> 2, na = P.g_na;
+            const float den = (float)(na - 1);
+            float4 v[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {  // launcher: kPanelRows * c4 <= 2 * blockDim.x
+                const int e = tid + it * (int)blockDim.x;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e - lr * c4) * 4;
+                    const int a = lr / bpb, i = lr - a * bpb;
+                    if (a < na && na > 1) {
+                        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int a2 = 0; a2 < na; ++a2) {
+                            const float4 q = *reinterpret_cast<const float4*>(D + (a2 * bpb + i) * ds + k);
+                            sm.x += q.x;
+                            sm.y += q.y;
+                            sm.z += q.z;
+                            sm.w += q.w;
+                        }
+                        const float4 me = *reinterpret_cast<const float4*>(D + lr * ds + k);
+                        v[it] = make_float4((sm.x - me.x) / den, (sm.y - me.y) / den, (sm.z - me.z) / den,
+                                            (sm.w - me.w) / den);
+                    }
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * (int)blockDim.x;
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e - lr * c4) * 4;
+                    *reinterpret_cast<float4*>(D + lr * ds + k) = v[it];
+                }
+            }
+            lds_barrier();
+        }
         // ---- row pass: D holds d(SiLU out); D <- dz, dgamma/dbeta column partials.  A row
         // lives in registers between the statistics and the dz pass.
         {
@@ -520,8 +651,8 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             for (int i = 0; i < RPW; ++i) {
                 const int lr = wave + i * nwaves;
                 if (lr < kPanelRows) {  // wave-uniform
-                    const int row = m0 + lr;
-                    const bool rv = row < P.m;
+                    const int row = rowmap[lr];
+                    const bool rv = row >= 0;
                     float xh[kBwdMaxCols], dxh[kBwdMaxCols];
                     float s1 = 0.f, s2 = 0.f, rstd = 0.f;
                     if (rv) {
@@ -595,18 +726,23 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             // slice partials are indexed by the tile's slot in this round
             panel_ksum(acc, part, tiles_round, ks, wave % tiles_round, s, lane, active);
             if (active && s == 0) {
+                int rw[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[r] = last ? rowmap[4 * quad + r] : -1;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int col = j * 32 + 16 * t + l16;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int lr = 4 * quad + r;
-                        const int row = m0 + lr;
+                        const int row = rw[r];
                         const float v = col < nout ? acc[t][r] : 0.f;
                         if (last) {
-                            if (col < nout && row < P.m) {
+                            if (col < nout && row >= 0) {
                                 float* o = P.dx + (size_t)row * P.lddx + col;
-                                *o = P.accumulate ? *o + v : v;
+                                const float tot = P.accumulate ? *o + v : v;
+                                *o = tot;
+                                if (P.has_cellb) lstm_cell_bwd_at(P.cellb, row, col, tot);
                             }
                         } else if (col < o16) {
                             E[lr * es + col] = v;
@@ -623,6 +759,7 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
 }
 
 int panel_bwd_blocks(int m) { return (int)cdiv(m, kPanelRows); }
+int panel_chain_blocks(int na, int nb) { return na >= 1 && na <= kPanelRows ? (int)cdiv(nb, kPanelRows / na) : 0; }
 
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     int waves = 8, pmax = 0, nmax = 0, prm = 0;
@@ -645,7 +782,13 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     p.off_prm = 2 * kPanelRows * pmax;
     p.off_colp = p.off_prm + prm + 16;
     p.off_part = p.off_colp + waves * 2 * nmax;
-    const size_t lds = (size_t)(p.off_part + (waves - 1) * 512) * sizeof(float);
+    p.off_rowmap = p.off_part + (waves - 1) * 512;
+    const size_t lds = (size_t)(p.off_rowmap + kPanelRows) * sizeof(float);
+    if (p.agg_at > 0 && (p.by_batch < 1 || p.g_na * p.by_batch > kPanelRows || p.agg_at >= p.nlayers ||
+                         !panel_chain_supported(p.g_na, p.layer[p.agg_at].n, 256))) {
+        set_error("panel backward: in-panel message mean outside its range");
+        return MARL_ELIMIT;
+    }
     if (lds > kPanelMaxLds) {
         set_error("panel backward: shape outside its range");
         return MARL_ELIMIT;
@@ -660,7 +803,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
                                            (int)kPanelMaxLds));
         raised = true;
     }
-    const unsigned pblocks = (unsigned)cdiv(p.m, kPanelRows);
+    const unsigned pblocks = p.by_batch > 0 ? (unsigned)cdiv(p.g_nb, p.by_batch) : (unsigned)cdiv(p.m, kPanelRows);
     prof_before(4, st);
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
