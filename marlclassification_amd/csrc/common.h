@@ -278,7 +278,7 @@ int launch_draw_episode(uint64_t seed, uint64_t offset, const uint64_t* offset_d
 
 // generic permuted copies used by pack / unpack
 struct PermDesc {
-    const float* src;
+    const float* src;    // null: dst is zero-filled
     float* dst;
     int rows, cols;      // dst logical extent
     int dst_ld;
@@ -286,7 +286,7 @@ struct PermDesc {
     int cd, cs1, cs2;    //            + (c / cd) * cs1 + (c % cd) * cs2
     const float* src2;   // optional: dst = src + src2 (same indexing), e.g. b_ih + b_hh
 };
-constexpr int kMaxPerm = 24;
+constexpr int kMaxPerm = 56;  // 64-byte descriptors: the batch stays under the 4 KB kernel-argument limit
 struct PermBatch {
     PermDesc d[kMaxPerm];
     int count;

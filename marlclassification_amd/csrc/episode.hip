@@ -893,20 +893,6 @@ static void fill_sample_args(const Ctx& c, const marl_config* cfg, int t, Sample
     }
 }
 
-static int load_state(const Ctx& c, const float* h, const float* cc_, const float* hc,
-                      const float* cca, const float* msg) {
-    const Dims& d = c.d;
-    MARL_TRY(launch_copy2d(h, d.n_b, c.Hs(0), d.ld_nb, d.R, d.n_b, c.st));
-    MARL_TRY(launch_copy2d(cc_, d.n_b, c.Cs(0), d.ld_nb, d.R, d.n_b, c.st));
-    MARL_TRY(launch_copy2d(hc, d.n_a, c.HCs(0), d.ld_na, d.R, d.n_a, c.st));
-    MARL_TRY(launch_copy2d(cca, d.n_a, c.CCs(0), d.ld_na, d.R, d.n_a, c.st));
-    if (msg)
-        MARL_TRY(launch_copy2d(msg, d.n_m, c.MSGs(0), d.ld_nm, d.R, d.n_m, c.st));
-    else
-        MARL_TRY(launch_fill(c.MSGs(0), d.R * d.ld_nm, 0.f, c.st));  // models.py:161-162
-    return MARL_OK;
-}
-
 // ---------------------------------------------------------------------------
 // pack / unpack
 // ---------------------------------------------------------------------------
@@ -943,6 +929,27 @@ static PermDesc perm(const float* src, float* dst, int rows, int cols, int dst_l
     p.src2 = src2;
     return p;
 }
+
+// plain strided copy (src null: zero fill) as a descriptor of the batched permute kernel
+static PermDesc copy_desc(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int cols) {
+    return perm(src, dst, (int)rows, cols, (int)ldd, 1, (int)lds, 0, 1, 1, 0);
+}
+
+// initial recurrent state -> slice 0 of the all-steps buffers, one launch
+static int load_state(const Ctx& c, const float* h, const float* cc_, const float* hc,
+                      const float* cca, const float* msg) {
+    const Dims& d = c.d;
+    PermQueue q(c.st);
+    q.push(copy_desc(h, d.n_b, c.Hs(0), d.ld_nb, d.R, d.n_b));
+    q.push(copy_desc(cc_, d.n_b, c.Cs(0), d.ld_nb, d.R, d.n_b));
+    q.push(copy_desc(hc, d.n_a, c.HCs(0), d.ld_na, d.R, d.n_a));
+    q.push(copy_desc(cca, d.n_a, c.CCs(0), d.ld_na, d.R, d.n_a));
+    // (no message: zeros, models.py:161-162 - the whole padded row)
+    q.push(copy_desc(msg, d.n_m, c.MSGs(0), d.ld_nm, d.R, msg ? d.n_m : d.ld_nm));
+    q.flush();
+    return q.rc;
+}
+
 
 static int pack_weights(const Dims& d, const WLayout& w, const float* const* params, float* W,
                         hipStream_t st) {
@@ -1061,10 +1068,17 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         }
     // ---- heads, batched over all steps -----------------------------------------------
     // prediction head (networks/prediction.py:11-14)
-    if (g_preds)
-        MARL_TRY(launch_copy2d(g_preds, d.nC, c.at(c.e.GPRED), d.ld_nC, NR, d.nC, st));
-    else
-        MARL_TRY(launch_fill(c.at(c.e.GPRED), NR * d.ld_nC, 0.f, st));
+    {   // output gradients into the padded layouts + the zero initial state gradients: one launch
+        PermQueue q(st);
+        q.push(copy_desc(g_preds, d.nC, c.at(c.e.GPRED), d.ld_nC, NR, g_preds ? d.nC : d.ld_nC));
+        q.push(copy_desc(g_values, 1, c.at(c.e.DVAL), 4, NR, g_values ? 1 : 4));
+        q.push(copy_desc(nullptr, 0, c.DHs(0), d.ld_nb, d.R, d.ld_nb));
+        q.push(copy_desc(nullptr, 0, c.DHCs(0), d.ld_na, d.R, d.ld_na));
+        q.push(copy_desc(nullptr, 0, c.at(c.e.DC), d.ld_nb, d.R, d.ld_nb));
+        q.push(copy_desc(nullptr, 0, c.at(c.e.DCC), d.ld_na, d.R, d.ld_na));
+        q.flush();
+        MARL_TRY(q.rc);
+    }
     MARL_TRY(gemm1(c, gemm_prob(c.at(c.e.GPRED), d.ld_nC, c.wt(MARL_P_PRE_W1), p4(d.nC), d.nC,
                                 c.at(c.e.DAQ1), d.ld_nlb, (int)NR, d.nlb)));
     MARL_TRY(tn(c, c.at(c.e.GPRED), d.ld_nC, c.at(c.e.AQ1), d.ld_nlb, MARL_P_PRE_W1, d.nC, d.nlb, NR, grads[MARL_P_PRE_B1]));
@@ -1072,10 +1086,6 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                     MARL_P_PRE_LNW, MARL_P_PRE_LNB, NR, d.nlb, grads, 0));
     MARL_TRY(tn(c, c.at(c.e.DAQ1), d.ld_nlb, c.Hs(1), d.ld_nb, MARL_P_PRE_W0, d.nlb, d.n_b, NR, grads[MARL_P_PRE_B0]));
     // critic head (networks/policy.py:23-27)
-    if (g_values)
-        MARL_TRY(launch_copy2d(g_values, 1, c.at(c.e.DVAL), 4, NR, 1, st));
-    else
-        MARL_TRY(launch_fill(c.at(c.e.DVAL), NR * 4, 0.f, st));
     MARL_TRY(tn(c, c.at(c.e.DVAL), 4, c.at(c.e.AC1), d.ld_nla, MARL_P_CRI_W1, 1, d.nla, NR, grads[MARL_P_CRI_B1]));
     if (d.nla <= 384) {
         MARL_TRY(ln_bwd_rank(c, c.at(c.e.DVAL), 4, 1, MARL_P_CRI_W1, c.at(c.e.ZC1), d.ld_nla,
@@ -1112,10 +1122,6 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         gemm_add_seg(pa, c.at(c.e.DAC1), d.ld_nla, c.wt(MARL_P_CRI_W0), d.ld_nla, d.nla);
         MARL_TRY(gemm2(c, ph, pa));
     }
-    MARL_TRY(launch_fill(c.DHs(0), d.R * d.ld_nb, 0.f, st));
-    MARL_TRY(launch_fill(c.DHCs(0), d.R * d.ld_na, 0.f, st));
-    MARL_TRY(launch_fill(c.at(c.e.DC), d.R * d.ld_nb, 0.f, st));
-    MARL_TRY(launch_fill(c.at(c.e.DCC), d.R * d.ld_na, 0.f, st));
 
     // ---- reverse-time loop over the recurrent chain ----------------------------------
     const size_t s_nmo = (size_t)d.R * d.ld_dbl, s_nm2 = (size_t)d.R * d.ld_nm2,

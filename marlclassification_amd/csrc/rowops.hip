@@ -1068,7 +1068,7 @@ __global__ void permute_kernel(const PermBatch B) {
         const int r = (int)(idx / d.cols), c = (int)(idx % d.cols);
         const int64_t so = (int64_t)(r / d.rd) * d.rs1 + (int64_t)(r % d.rd) * d.rs2 +
                            (int64_t)(c / d.cd) * d.cs1 + (int64_t)(c % d.cd) * d.cs2;
-        float v = d.src[so];
+        float v = d.src ? d.src[so] : 0.f;
         if (d.src2) v += d.src2[so];
         d.dst[(int64_t)r * d.dst_ld + c] = v;
     }
