@@ -282,15 +282,35 @@ __global__ __launch_bounds__(1024) void ln_silu_bwd_reg_kernel(
         for (int j = 0; j < 4; ++j) bw[u][j] = (c < n && j < kin) ? bt[(size_t)c * ldbt + j] : 0.f;
     }
     const float inv_n = 1.0f / (float)n;
-    for (int rr = 0; rr < rpw; ++rr) {
-        const int64_t row = ((int64_t)blockIdx.x * nwaves + wave) * rpw + rr;
-        if (row >= m) break;
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        const float* zr = z + row * ldz;
-        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    // The loads of row rr + 1 are issued before row rr is processed: a wave keeps two rows in
+    // flight (the pass is HBM-latency bound - one row at a time leaves the memory pipe idle during
+    // the statistics and the dependent stores).
+    const int64_t row_base = ((int64_t)blockIdx.x * nwaves + wave) * rpw;
+    float zc[U], dc[U], gvc[4], mean_c = 0.f, rstd_c = 0.f;
+    auto fetch = [&](int64_t row, float (&zv)[U], float (&dv)[U], float (&gv)[4], float& mean, float& rstd) {
+        const bool ok = row < m;
+        const int64_t r = ok ? row : 0;
+        mean = stats[r * 2];
+        rstd = stats[r * 2 + 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < kin) gv[j] = g[row * ldg + j];
+        for (int j = 0; j < 4; ++j) gv[j] = j < kin ? g[r * ldg + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * u;
+            zv[u] = c < n ? z[r * ldz + c] : 0.f;
+            dv[u] = (kin == 0 && c < n) ? da[r * ldda + c] : 0.f;
+        }
+    };
+    constexpr bool PF = U >= 2;  // (narrow rows: measured slower with the prefetch)
+    if (PF && row_base < m) fetch(row_base, zc, dc, gvc, mean_c, rstd_c);
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = row_base + rr;
+        if (row >= m) break;
+        if (!PF) fetch(row, zc, dc, gvc, mean_c, rstd_c);
+        float zn[U], dn[U], gvn[4], mean_n = 0.f, rstd_n = 0.f;
+        const bool more = PF && rr + 1 < rpw && row + 1 < m;
+        if (more) fetch(row + 1, zn, dn, gvn, mean_n, rstd_n);
+        const float mean = mean_c, rstd = rstd_c;
         float xh[U], dxh[U];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -300,10 +320,10 @@ __global__ __launch_bounds__(1024) void ln_silu_bwd_reg_kernel(
             if (c < n) {
                 float dav;
                 if (kin > 0)
-                    dav = ((gv[0] * bw[u][0] + gv[1] * bw[u][1]) + gv[2] * bw[u][2]) + gv[3] * bw[u][3];
+                    dav = ((gvc[0] * bw[u][0] + gvc[1] * bw[u][1]) + gvc[2] * bw[u][2]) + gvc[3] * bw[u][3];
                 else
-                    dav = da[row * ldda + c];
-                xh[u] = (zr[c] - mean) * rstd;
+                    dav = dc[u];
+                xh[u] = (zc[u] - mean) * rstd;
                 const float dy = dav * silu_grad(gam[u] * xh[u] + bet[u]);
                 dxh[u] = dy * gam[u];
                 s1 += dxh[u];
@@ -318,6 +338,17 @@ __global__ __launch_bounds__(1024) void ln_silu_bwd_reg_kernel(
         for (int u = 0; u < U; ++u) {
             const int c = lane + 64 * u;
             if (c < n) dzr[c] = rstd * (dxh[u] - m1 - xh[u] * m2);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                zc[u] = zn[u];
+                dc[u] = dn[u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gvc[j] = gvn[j];
+            mean_c = mean_n;
+            rstd_c = rstd_n;
         }
     }
     float* ga = sacc + (size_t)wave * 2 * n;
