@@ -837,6 +837,123 @@ __global__ __launch_bounds__(1024) void gn_silu_bwd_flat_kernel(
     }
 }
 
+// Register-resident form of the flat kernel for rows of exactly 64 * U * NE elements (NE <= 4):
+// z and da are read ONCE (the row lives in registers between the statistics and the dz pass),
+// the next row's loads are issued before the current row is processed, and the per-channel
+// dgamma / dbeta sums stay in registers over all rows of the wave (one cross-lane reduction at
+// the end instead of one per row).
+template <int U, int NE>
+__global__ __launch_bounds__(1024) void gn_silu_bwd_rowreg_kernel(
+    const float* __restrict__ da, int64_t ldda, int da_chw, const float* __restrict__ z,
+    const float* __restrict__ stats, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dz, float* __restrict__ part,
+    int64_t rows, int P, int C, int G, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];  // [waves][2][C]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int Cg = C / G;
+    const int E = P * C;
+    const int lc = C < 64 ? C : 64;  // lanes per position
+    const float inv_cnt = 1.0f / (float)(P * Cg);
+    float gm[U], bt[U], pga[U], pgb[U];
+    int ch[U], grp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ch[u] = (lane % lc) + 64 * u;
+        grp[u] = ch[u] / Cg;
+        gm[u] = gamma[ch[u]];
+        bt[u] = beta[ch[u]];
+        pga[u] = pgb[u] = 0.f;
+    }
+    // element (i, u) of a lane: e = 64 * U * i + lane + 64 * u -> position e / C, channel ch[u]
+    struct Row {
+        float zv[NE][U], dv[NE][U], mean[U], rstd[U];
+    };
+    auto fetch = [&](int64_t row, Row& r) {
+        const int64_t rr = row < rows ? row : 0;
+        const float* zr = z + rr * (int64_t)E;
+        const float* dar = da + rr * ldda;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r.mean[u] = stats[(rr * G + grp[u]) * 2];
+            r.rstd[u] = stats[(rr * G + grp[u]) * 2 + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = 64 * U * i + lane + 64 * u;
+                r.zv[i][u] = zr[e];
+                r.dv[i][u] = dar[da_chw ? (int64_t)ch[u] * P + e / C : (int64_t)e];
+            }
+    };
+    const int64_t row_base = ((int64_t)blockIdx.x * nwaves + wave) * rpw;
+    Row cur, nxt;
+    if (row_base < rows) fetch(row_base, cur);
+    for (int rr = 0; rr < rpw; ++rr) {
+        const int64_t row = row_base + rr;
+        if (row >= rows) break;
+        const bool more = rr + 1 < rpw && row + 1 < rows;
+        if (more) fetch(row + 1, nxt);
+        float xh[NE][U], dxh[NE][U], s1[U], s2[U], pg[U], pb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s1[u] = s2[u] = pg[u] = pb[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xh[i][u] = (cur.zv[i][u] - cur.mean[u]) * cur.rstd[u];
+                const float dy = cur.dv[i][u] * silu_grad(gm[u] * xh[i][u] + bt[u]);
+                dxh[i][u] = dy * gm[u];
+                s1[u] += dxh[i][u];
+                s2[u] += dxh[i][u] * xh[i][u];
+                pg[u] += dy * xh[i][u];
+                pb[u] += dy;
+            }
+        float* dzr = dz + row * (int64_t)E;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // group sums: lanes of the same group (bits below log2(Cg)) x all position bits
+            for (int o = 1; o < Cg && o < 64; o <<= 1) {
+                s1[u] += __shfl_xor(s1[u], o);
+                s2[u] += __shfl_xor(s2[u], o);
+            }
+            for (int o = lc; o < 64; o <<= 1) {
+                s1[u] += __shfl_xor(s1[u], o);
+                s2[u] += __shfl_xor(s2[u], o);
+            }
+            pga[u] += pg[u];
+            pgb[u] += pb[u];
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                dzr[64 * U * i + lane + 64 * u] =
+                    cur.rstd[u] * (dxh[i][u] - s1[u] * inv_cnt - xh[i][u] * s2[u] * inv_cnt);
+        }
+        if (more) cur = nxt;
+    }
+    float* ga = sacc + (size_t)wave * 2 * C;
+    float* gb = ga + C;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        for (int o = lc; o < 64; o <<= 1) {  // lanes of the same channel at other positions
+            pga[u] += __shfl_xor(pga[u], o);
+            pgb[u] += __shfl_xor(pgb[u], o);
+        }
+        if (lane < lc) {  // single owner per channel
+            ga[ch[u]] = pga[u];
+            gb[ch[u]] = pgb[u];
+        }
+    }
+    __syncthreads();
+    float* p = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sacc[(size_t)w * 2 * C + c];
+        p[c] = t;
+    }
+}
+
 int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z,
                        const float* stats, const float* gamma, const float* beta, float* dz,
                        float* part, int64_t rows, int P, int C, int G, hipStream_t st) {
@@ -852,6 +969,33 @@ int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z
     if (pow2 && !getenv("MARL_GN_OLD")) {
         const dim3 grid((unsigned)gn_bwd_blocks(rows, C)), blk(64 * w);
         const size_t lds = (size_t)w * 2 * C * sizeof(float);
+        const int U = C <= 64 ? 1 : C / 64, E = P * C;
+        if (E % (64 * U) == 0 && E / (64 * U) <= 4 && tune_get("gn_rowreg", 1)) {
+            const int ne = E / (64 * U);
+#define MARL_GN_RR(U_, NE_)                                                                        \
+    hipLaunchKernelGGL((gn_silu_bwd_rowreg_kernel<U_, NE_>), grid, blk, lds, st, da, ldda, da_chw, z, \
+                       stats, gamma, beta, dz, part, rows, P, C, G, rpw)
+#define MARL_GN_RRU(U_)        \
+    if (ne == 1)               \
+        MARL_GN_RR(U_, 1);     \
+    else if (ne == 2)          \
+        MARL_GN_RR(U_, 2);     \
+    else if (ne == 3)          \
+        MARL_GN_RR(U_, 3);     \
+    else                       \
+        MARL_GN_RR(U_, 4)
+            if (U == 1) {
+                MARL_GN_RRU(1);
+            } else if (U == 2) {
+                MARL_GN_RRU(2);
+            } else {
+                MARL_GN_RRU(4);
+            }
+#undef MARL_GN_RRU
+#undef MARL_GN_RR
+            MARL_LAUNCH_CHECK();
+            return MARL_OK;
+        }
         if (C <= 64)
             hipLaunchKernelGGL(gn_silu_bwd_flat_kernel<1>, grid, blk, lds, st, da, ldda, da_chw, z,
                                stats, gamma, beta, dz, part, rows, P, C, G, rpw);
