@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void ln_silu_fwd_kernel(const float* __restric
     }
 }
 
-// widths <= 64 * U: the row is read once and stays in registers for both statistics passes
+// widths <= 64 * U: the row is read once and stays in registers for both statistics passes.
+// A wave owns TWO rows (row and row + half): both rows' loads are in flight together and the
+// affine parameters are fetched once.
 template <int U>
 __global__ __launch_bounds__(256) void ln_silu_fwd_reg_kernel(const float* __restrict__ z, int ldz,
                                                               const float* __restrict__ gamma,
@@ -124,46 +126,57 @@ __global__ __launch_bounds__(256) void ln_silu_fwd_reg_kernel(const float* __res
                                                               float* __restrict__ stats, int64_t m,
                                                               int n, const float* __restrict__ wdot,
                                                               const float* __restrict__ bdot,
-                                                              float* __restrict__ dot_out) {
+                                                              float* __restrict__ dot_out, int64_t half) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
-    const float* zr = z + row * ldz;
-    float v[U];
-    float s = 0.f;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row0 >= half) return;
+    const int64_t rows[2] = {row0, row0 + half};
+    const bool ok1 = rows[1] < m;
+    float v[2][U], gm[U], bt[U], wd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = lane + 64 * u;
-        v[u] = c < n ? zr[c] : 0.f;
-        s += v[u];
+        v[0][u] = c < n ? z[rows[0] * ldz + c] : 0.f;
+        v[1][u] = (c < n && ok1) ? z[rows[1] * ldz + c] : 0.f;
+        gm[u] = c < n ? gamma[c] : 0.f;
+        bt[u] = c < n ? beta[c] : 0.f;
+        wd[u] = (c < n && wdot) ? wdot[c] : 0.f;
     }
-    const float mean = wave_sum(s) / (float)n;
-    float q = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const float d = (lane + 64 * u < n) ? v[u] - mean : 0.f;
-        v[u] = d;
-        q += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + 1e-5f);
-    float* orow = out + row * ldo;
-    float dot = 0.f;
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !ok1) break;
+        const int64_t row = rows[k];
+        float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int c = lane + 64 * u;
-        if (c < n) {
-            const float a = silu_f(v[u] * rstd * gamma[c] + beta[c]);
-            orow[c] = a;
-            if (wdot) dot += a * wdot[c];
+        for (int u = 0; u < U; ++u) s += v[k][u];
+        const float mean = wave_sum(s) / (float)n;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float d = (lane + 64 * u < n) ? v[k][u] - mean : 0.f;
+            v[k][u] = d;
+            q += d * d;
         }
-    }
-    if (stats && lane == 0) {
-        stats[row * 2] = mean;
-        stats[row * 2 + 1] = rstd;
-    }
-    if (wdot) {  // a one-output layer on top (critic value) comes for free from the registers
-        dot = wave_sum(dot);
-        if (lane == 0) dot_out[row] = dot + bdot[0];
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + 1e-5f);
+        float* orow = out + row * ldo;
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * u;
+            if (c < n) {
+                const float a = silu_f(v[k][u] * rstd * gm[u] + bt[u]);
+                orow[c] = a;
+                dot += a * wd[u];
+            }
+        }
+        if (stats && lane == 0) {
+            stats[row * 2] = mean;
+            stats[row * 2 + 1] = rstd;
+        }
+        if (wdot) {  // a one-output layer on top (critic value) comes for free from the registers
+            dot = wave_sum(dot);
+            if (lane == 0) dot_out[row] = dot + bdot[0];
+        }
     }
 }
 
@@ -171,17 +184,18 @@ int launch_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float*
                        int ldo, float* stats, int64_t m, int n, hipStream_t st, const float* wdot,
                        const float* bdot, float* dot_out) {
     if (m <= 0) return MARL_OK;
-    const dim3 grid((unsigned)cdiv(m, 4)), blk(256);
+    const int64_t half = (m + 1) / 2;  // the register kernels: two rows per wave
+    dim3 grid((unsigned)cdiv(n <= 384 ? half : m, 4)), blk(256);
     if (wdot && n > 384) {
         set_error("fused row dot needs a LayerNorm width <= 384");
         return MARL_ELIMIT;
     }
     if (n <= 128)
         hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<2>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
-                           stats, m, n, wdot, bdot, dot_out);
+                           stats, m, n, wdot, bdot, dot_out, half);
     else if (n <= 384)
         hipLaunchKernelGGL(ln_silu_fwd_reg_kernel<6>, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo,
-                           stats, m, n, wdot, bdot, dot_out);
+                           stats, m, n, wdot, bdot, dot_out, half);
     else
         hipLaunchKernelGGL(ln_silu_fwd_kernel, grid, blk, 0, st, z, ldz, gamma, beta, out, ldo, stats,
                            m, n);
