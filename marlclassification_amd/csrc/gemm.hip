@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 // TN: contraction over rows.  LDS tiles are [BK rows][BM or BN columns]; the MFMA
 // fragments are ds_read_b32 with consecutive lanes on consecutive columns.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                       const float* __restrict__ B, int ldb,
                                                       float* __restrict__ out, int ldo,
@@ -447,7 +447,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int fk = lane >> 5;
     if (T > 0) MARL_TN_LOAD(0)
     for (int tile = 0; tile < T; ++tile) {
-        const int buf = tile & 1;
+        // NBUF == 1: ONE LDS stage (32 KB for 128-wide tiles) and a second barrier per tile.  The
+        // 168 registers of the 128-wide plan allow three workgroups per CU, two stages of LDS only
+        // two: with one stage all 768 workgroups of a launch are resident at once (measured
+        // 2.07 -> 2.00 ms for the weight gradients of an iteration).
+        const int buf = NBUF == 2 ? (tile & 1) : 0;
+        if (NBUF == 1 && tile > 0) lds_barrier();  // every wave is done reading the previous tile
         {
             float* As_ = smem + buf * BK * (BM + BN);
             float* Bs_ = As_ + BK * BM;
@@ -979,7 +984,11 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, 2, 2, BK_>), grid, dim3(256),                 \
                        (size_t)2 * BK_ * 2 * BM_ * sizeof(float), st, a, lda, b, ldb, out, ldo, \
                        stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz)
-    if (p.bm == 128 && tbk == 32)
+    if (p.bm == 128 && tbk == 32 && tune_get("tn_bufs", 1) == 1)
+        hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256),
+                           (size_t)32 * 2 * 128 * sizeof(float), st, a, lda, b, ldb, out, ldo, stride, ni, nj,
+                           rows, p.rows_per_split, csum, gx, gy, gz);
+    else if (p.bm == 128 && tbk == 32)
         MARL_TN_LAUNCH(128, 32);
     else if (p.bm == 128)
         MARL_TN_LAUNCH(128, 16);
