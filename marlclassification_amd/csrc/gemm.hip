@@ -134,52 +134,71 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
     // per load).  Only the LAST K tile of a segment can reach past round4(K): there the chunk
     // address is clamped and the B side is zeroed when the tile goes to LDS (weights are
     // finite, so finite-garbage * 0 is exact); all other tiles take the mask-free path.
+    // two sets of staging registers (X, Y): the small-tile plan keeps TWO tiles in flight
     float4 raX0, raX1, raX2, raX3, rbX0, rbX1, rbX2, rbX3;
-    float mkX = 1.f;
-    bool masked = false;  // uniform: the tile held in the staging registers is a tail tile
-#define MARL_LOADA(idx_, d_) \
-    if (A_CH > (idx_)) raX##idx_ = *reinterpret_cast<const float4*>(abase + (aofX##idx_ + (d_)));
-#define MARL_LOADB(idx_, d_) \
-    if (B_CH > (idx_)) rbX##idx_ = *reinterpret_cast<const float4*>(bbase + (bofX##idx_ + (d_)));
-#define MARL_LOAD_ALL(d_)                                                                  \
-    MARL_LOADA(0, d_) MARL_LOADA(1, d_) MARL_LOADA(2, d_) MARL_LOADA(3, d_)                \
-    MARL_LOADB(0, d_) MARL_LOADB(1, d_) MARL_LOADB(2, d_) MARL_LOADB(3, d_)
-#define MARL_LOAD_TILE(tile_)                                                              \
+    float4 raY0, raY1, raY2, raY3, rbY0, rbY1, rbY2, rbY3;
+    float mkX = 1.f, mkY = 1.f;
+    bool maskedX = false, maskedY = false;  // uniform: the tile held in the set is a tail tile
+#define MARL_LOADA(S_, idx_, d_) \
+    if (A_CH > (idx_)) ra##S_##idx_ = *reinterpret_cast<const float4*>(abase + (aofX##idx_ + (d_)));
+#define MARL_LOADB(S_, idx_, d_) \
+    if (B_CH > (idx_)) rb##S_##idx_ = *reinterpret_cast<const float4*>(bbase + (bofX##idx_ + (d_)));
+#define MARL_LOAD_ALL(S_, d_)                                                              \
+    MARL_LOADA(S_, 0, d_) MARL_LOADA(S_, 1, d_) MARL_LOADA(S_, 2, d_) MARL_LOADA(S_, 3, d_) \
+    MARL_LOADB(S_, 0, d_) MARL_LOADB(S_, 1, d_) MARL_LOADB(S_, 2, d_) MARL_LOADB(S_, 3, d_)
+#define MARL_LOAD_TILE_S(S_, tile_)                                                        \
     {                                                                                      \
         if ((tile_) == t0) MARL_SET_SEG(1)                                                 \
         const int k0_ = ((tile_) >= t0 ? (tile_) - t0 : (tile_)) * BK;                     \
-        masked = k0_ + BK > K4cur;                                                         \
-        if (!masked) {                                                                     \
-            MARL_LOAD_ALL(0u)                                                              \
-        } else {                                                                           \
-            const int k_ = k0_ + koff;                                                     \
-            const uint32_t d_ = k_ < K4cur ? 0u : (uint32_t)((K4cur - 4 - k_) * 4);        \
-            mkX = k_ < K4cur ? 1.f : 0.f;                                                  \
-            MARL_LOAD_ALL(d_)                                                              \
-        }                                                                                  \
+        masked##S_ = k0_ + BK > K4cur;                                                     \
+        const int k_ = k0_ + koff;                                                         \
+        const uint32_t d_ = (!masked##S_ || k_ < K4cur) ? 0u : (uint32_t)((K4cur - 4 - k_) * 4); \
+        mk##S_ = (!masked##S_ || k_ < K4cur) ? 1.f : 0.f;                                  \
+        MARL_LOAD_ALL(S_, d_)                                                              \
         abase += BK * 4;                                                                   \
         bbase += BK * 4;                                                                   \
     }
-#define MARL_STOREA(idx_)                                                                  \
-    if (A_CH > (idx_))                                                                     \
-        *reinterpret_cast<float4*>(As_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = raX##idx_;
-#define MARL_STOREB(idx_)                                                                  \
-    if (B_CH > (idx_)) {                                                                   \
-        if (masked) {                                                                      \
-            rbX##idx_.x *= mkX;                                                            \
-            rbX##idx_.y *= mkX;                                                            \
-            rbX##idx_.z *= mkX;                                                            \
-            rbX##idx_.w *= mkX;                                                            \
-        }                                                                                  \
-        *reinterpret_cast<float4*>(Bs_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = rbX##idx_; \
+#define MARL_LOAD_TILE(tile_) MARL_LOAD_TILE_S(X, tile_)
+// UNCONDITIONAL form for the two-tiles-ahead loop: a load behind a branch makes the compiler wait
+// for ALL outstanding loads (vmcnt(0)) wherever it needs the older set, which would serialise
+// the two sets again.  Tiles past the end re-read the last tile (valid addresses, never stored).
+#define MARL_LOAD_TILE_U(S_, tile_)                                                        \
+    {                                                                                      \
+        const bool live_ = (tile_) < T;                                                    \
+        if (live_ && (tile_) == t0) MARL_SET_SEG(1)                                        \
+        const int tc_ = live_ ? (tile_) : T - 1;                                           \
+        const int k0_ = (tc_ >= t0 ? tc_ - t0 : tc_) * BK;                                 \
+        masked##S_ = k0_ + BK > K4cur;                                                     \
+        const int k_ = k0_ + koff;                                                         \
+        const uint32_t d_ = (!masked##S_ || k_ < K4cur) ? 0u : (uint32_t)((K4cur - 4 - k_) * 4); \
+        mk##S_ = (!masked##S_ || k_ < K4cur) ? 1.f : 0.f;                                  \
+        abase -= live_ ? 0 : BK * 4; /* (64-bit base: the 32-bit lane offsets must not wrap) */ \
+        bbase -= live_ ? 0 : BK * 4;                                                       \
+        MARL_LOAD_ALL(S_, d_)                                                              \
+        abase += BK * 4;                                                                   \
+        bbase += BK * 4;                                                                   \
     }
-#define MARL_STORE_TILE(buf_)                                                              \
+#define MARL_STOREA(S_, idx_)                                                              \
+    if (A_CH > (idx_))                                                                     \
+        *reinterpret_cast<float4*>(As_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = ra##S_##idx_;
+#define MARL_STOREB(S_, idx_)                                                              \
+    if (B_CH > (idx_)) {                                                                   \
+        if (masked##S_) {                                                                  \
+            rb##S_##idx_.x *= mk##S_;                                                      \
+            rb##S_##idx_.y *= mk##S_;                                                      \
+            rb##S_##idx_.z *= mk##S_;                                                      \
+            rb##S_##idx_.w *= mk##S_;                                                      \
+        }                                                                                  \
+        *reinterpret_cast<float4*>(Bs_ + ((tid + 256 * (idx_)) / KC) * LDS_K + koff) = rb##S_##idx_; \
+    }
+#define MARL_STORE_TILE_S(S_, buf_)                                                        \
     {                                                                                      \
         float* As_ = smem + (buf_) * BUF + grp * BM * LDS_K;                               \
         float* Bs_ = smem + (buf_) * BUF + (GROUPS * BM + grp * (BN / GROUPS)) * LDS_K;    \
-        MARL_STOREA(0) MARL_STOREA(1) MARL_STOREA(2) MARL_STOREA(3)                        \
-        MARL_STOREB(0) MARL_STOREB(1) MARL_STOREB(2) MARL_STOREB(3)                        \
+        MARL_STOREA(S_, 0) MARL_STOREA(S_, 1) MARL_STOREA(S_, 2) MARL_STOREA(S_, 3)        \
+        MARL_STOREB(S_, 0) MARL_STOREB(S_, 1) MARL_STOREB(S_, 2) MARL_STOREB(S_, 3)        \
     }
+#define MARL_STORE_TILE(buf_) MARL_STORE_TILE_S(X, buf_)
     // Matrix phase: all fragments of an 8-deep K group are read first, then the MFMAs walk the
     // accumulators round-robin (k-major), so that consecutive matrix instructions never hit
     // the same accumulator and nothing else is issued between them.
@@ -226,7 +245,26 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 
     MARL_SET_SEG(0)
     MARL_LOAD_TILE(0)
-    if (GROUPS == 1) {
+    constexpr bool PF2 = GROUPS == 1 && !LSTM && A_CH + B_CH <= 4;
+    if (PF2) {
+        MARL_LOAD_TILE_U(Y, 1)
+        int tile = 0;
+        for (; tile + 1 < T; tile += 2) {  // pairs of tiles: no branch around any load
+            MARL_STORE_TILE_S(X, 0)
+            lds_barrier();
+            MARL_LOAD_TILE_U(X, tile + 2)
+            MARL_COMPUTE_TILE(0)
+            MARL_STORE_TILE_S(Y, 1)
+            lds_barrier();
+            MARL_LOAD_TILE_U(Y, tile + 3)
+            MARL_COMPUTE_TILE(1)
+        }
+        if (tile < T) {  // odd tile count: the last tile sits in X
+            MARL_STORE_TILE_S(X, 0)
+            lds_barrier();
+            MARL_COMPUTE_TILE(0)
+        }
+    } else if (GROUPS == 1) {
         // One barrier per tile: LDS buffer b was last read two tiles ago and every wave has
         // passed the previous tile's barrier only after finishing those reads.
         for (int tile = 0; tile < T; ++tile) {
@@ -269,6 +307,9 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 #undef MARL_LOADB
 #undef MARL_LOAD_ALL
 #undef MARL_LOAD_TILE
+#undef MARL_LOAD_TILE_S
+#undef MARL_LOAD_TILE_U
+#undef MARL_STORE_TILE_S
 #undef MARL_STOREA
 #undef MARL_STOREB
 #undef MARL_STORE_TILE
