@@ -162,16 +162,17 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
     float* Y = lds + B.off_panel1;
     float* part = lds + B.off_part;
     float* prm = lds + B.off_prm;  // [layer][bias | gamma | beta][n] staged once
-    {
-        int off = 0;
-        for (int l = 0; l < P.nlayers; ++l) {
-            const int n = P.layer[l].n;
-            for (int c = tid; c < n; c += blockDim.x) {
-                prm[off + c] = P.layer[l].bias[c];
-                prm[off + n + c] = P.layer[l].gamma[c];
-                prm[off + 2 * n + c] = P.layer[l].beta[c];
-            }
-            off += 3 * n;
+    // The per-channel vectors of EVERY layer and the input rows are requested before anything is
+    // waited for (one round trip to L2 at the head of the kernel instead of one per layer plus
+    // one per staging pass); the LDS stores follow the staging below.  n <= 32 * waves <= threads.
+    float pv[kPanelMaxLayers][3];
+#pragma unroll
+    for (int l = 0; l < kPanelMaxLayers; ++l) {
+        pv[l][0] = pv[l][1] = pv[l][2] = 0.f;
+        if (l < P.nlayers && tid < P.layer[l].n) {
+            pv[l][0] = P.layer[l].bias[tid];
+            pv[l][1] = P.layer[l].gamma[tid];
+            pv[l][2] = P.layer[l].beta[tid];
         }
     }
 
@@ -219,12 +220,46 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                 *reinterpret_cast<float4*>(X + lr * xs + k) = v;
             }
         } else {
-            for (int e = tid; e < kPanelRows * c4; e += blockDim.x) {
+            float4 xv[2];  // the first two passes' loads fly together
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * (int)blockDim.x;
+                xv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e % c4) * 4;
+                    const int r = rowmap[lr];
+                    if (r >= 0 && k < K4) xv[it] = *reinterpret_cast<const float4*>(P.x + (size_t)r * P.ldx + k);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * (int)blockDim.x;
+                if (e < kPanelRows * c4) {
+                    const int lr = e / c4, k = (e % c4) * 4;
+                    *reinterpret_cast<float4*>(X + lr * xs + k) = xv[it];
+                }
+            }
+            for (int e = tid + 2 * (int)blockDim.x; e < kPanelRows * c4; e += blockDim.x) {
                 const int lr = e / c4, k = (e % c4) * 4;
                 const int r = rowmap[lr];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r >= 0 && k < K4) v = *reinterpret_cast<const float4*>(P.x + (size_t)r * P.ldx + k);
                 *reinterpret_cast<float4*>(X + lr * xs + k) = v;
+            }
+        }
+    }
+    {
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < kPanelMaxLayers; ++l) {
+            if (l < P.nlayers) {
+                const int n = P.layer[l].n;
+                if (tid < n) {
+                    prm[off + tid] = pv[l][0];
+                    prm[off + n + tid] = pv[l][1];
+                    prm[off + 2 * n + tid] = pv[l][2];
+                }
+                off += 3 * n;
             }
         }
     }
@@ -534,14 +569,27 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
 
     // LayerNorm affine parameters of every layer -> LDS; d(a_last) panel -> D
     {
-        int off = 0;
-        for (int l = 0; l < P.nlayers; ++l) {
-            const int n = P.layer[l].n;
-            for (int c = tid; c < n; c += blockDim.x) {
-                prm[off + c] = P.layer[l].gamma[c];
-                prm[off + n + c] = P.layer[l].beta[c];
+        // (all layers' vectors requested before anything is waited for; n <= 384 <= threads)
+        float pv[kPanelMaxLayers][2];
+#pragma unroll
+        for (int l = 0; l < kPanelMaxLayers; ++l) {
+            pv[l][0] = pv[l][1] = 0.f;
+            if (l < P.nlayers && tid < P.layer[l].n) {
+                pv[l][0] = P.layer[l].gamma[tid];
+                pv[l][1] = P.layer[l].beta[tid];
             }
-            off += 2 * n;
+        }
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < kPanelMaxLayers; ++l) {
+            if (l < P.nlayers) {
+                const int n = P.layer[l].n;
+                if (tid < n) {
+                    prm[off + tid] = pv[l][0];
+                    prm[off + n + tid] = pv[l][1];
+                }
+                off += 2 * n;
+            }
         }
         const int n = P.layer[0].n, ds = panel_stride(n), n16 = (n + 15) & ~15, c4 = n16 >> 2;
         const int n4 = (n + 3) & ~3;
