@@ -635,6 +635,26 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
     }
     lds_barrier();
 
+    // The saved pre-LayerNorm rows (and statistics) of a layer are requested one layer ahead: the
+    // two rows of this wave for layer l + 1 fly while layer l's dX product runs.  Unconditional
+    // loads (padding rows read row 0) so that no wait is widened by a branch.
+    float zpre[2][kBwdMaxCols], mpre[2], rpre[2];
+    auto zfetch = [&](const PanelBwdLayer& L) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = wave + i * nwaves;
+            const int row = lr < kPanelRows ? rowmap[lr] : -1;
+            const size_t rr = row < 0 ? 0 : (size_t)row;
+            mpre[i] = L.stats[rr * 2];
+            rpre[i] = L.stats[rr * 2 + 1];
+#pragma unroll
+            for (int u = 0; u < kBwdMaxCols; ++u) {
+                const int c = lane + 64 * u;
+                zpre[i][u] = c < L.n ? L.z[rr * L.ldz + c] : 0.f;
+            }
+        }
+    };
+    zfetch(P.layer[0]);
     int prm_off = 0;
     for (int l = 0; l < P.nlayers; ++l) {
         const PanelBwdLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
@@ -704,15 +724,14 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
                     float xh[kBwdMaxCols], dxh[kBwdMaxCols];
                     float s1 = 0.f, s2 = 0.f, rstd = 0.f;
                     if (rv) {
-                        const float mean = Lr.stats[(size_t)row * 2];
-                        rstd = Lr.stats[(size_t)row * 2 + 1];
-                        const float* zr = Lr.z + (size_t)row * Lr.ldz;
+                        const float mean = mpre[i];
+                        rstd = rpre[i];
 #pragma unroll
                         for (int u = 0; u < kBwdMaxCols; ++u) {
                             const int c = lane + 64 * u;
                             xh[u] = dxh[u] = 0.f;
                             if (c < n) {
-                                xh[u] = (zr[c] - mean) * rstd;
+                                xh[u] = (zpre[i][u] - mean) * rstd;
                                 const float dy = D[lr * ds + c] * silu_grad_p(g[u] * xh[u] + bt[u]);
                                 dxh[u] = dy * g[u];
                                 s1 += dxh[u];
@@ -756,6 +775,7 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             for (int w = 0; w < nwaves; ++w) t += colp[(size_t)w * 2 * n + c];
             Lr.part[(size_t)blockIdx.x * 2 * n + c] = t;
         }
+        if (l + 1 < P.nlayers) zfetch(P.layer[l + 1]);
         // ---- dX = dz * W: out tiles over k_in columns, contraction over n
         const int nout = Lr.k_in, nt = (nout + 31) >> 5;
         const int ks = panel_ksplit(n, nt, nwaves);
