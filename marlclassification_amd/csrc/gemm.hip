@@ -246,7 +246,31 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
     MARL_SET_SEG(0)
     MARL_LOAD_TILE(0)
     constexpr bool PF2 = GROUPS == 1 && !LSTM && A_CH + B_CH <= 4;
-    if (PF2) {
+    // 128-wide tiles: the same two-tiles-ahead loads with ONE LDS stage (a second barrier per tile)
+    // - 168 registers allow three workgroups per CU, two 37 KB stages only two (-1.5 % on the class)
+    constexpr bool PF2S = GROUPS == 1 && !LSTM && A_CH + B_CH > 4;
+    if (PF2S && batch.single_buf) {
+        MARL_LOAD_TILE_U(Y, 1)
+        int tile = 0;
+        for (; tile + 1 < T; tile += 2) {
+            if (tile > 0) lds_barrier();
+            MARL_STORE_TILE_S(X, 0)
+            lds_barrier();
+            MARL_LOAD_TILE_U(X, tile + 2)
+            MARL_COMPUTE_TILE(0)
+            lds_barrier();
+            MARL_STORE_TILE_S(Y, 0)
+            lds_barrier();
+            MARL_LOAD_TILE_U(Y, tile + 3)
+            MARL_COMPUTE_TILE(0)
+        }
+        if (tile < T) {
+            if (tile > 0) lds_barrier();
+            MARL_STORE_TILE_S(X, 0)
+            lds_barrier();
+            MARL_COMPUTE_TILE(0)
+        }
+    } else if (PF2) {
         MARL_LOAD_TILE_U(Y, 1)
         int tile = 0;
         for (; tile + 1 < T; tile += 2) {  // pairs of tiles: no branch around any load
@@ -776,13 +800,15 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     // problems would load the XCDs unevenly (measured slower), they keep the plain order.
     batch.xcd_map = xcd_map_enabled() || (batch.count == 1 && !LSTM && tune_get("nt_xcd", 1));
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
-    constexpr size_t lds = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
+    constexpr size_t lds2 = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
+    batch.single_buf = GROUPS == 1 && !LSTM && BM == 128 && tune_get("nt_single", 1);
+    const size_t lds = batch.single_buf ? lds2 / 2 : lds2;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, GROUPS>;
-    if (lds > 64 * 1024) {
+    if (lds2 > 64 * 1024) {
         static bool raised = false;  // opt in to > 64 KiB of dynamic LDS once per kernel
         if (!raised) {
             MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             raised = true;
         }
     }
