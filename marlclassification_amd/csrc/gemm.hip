@@ -628,8 +628,89 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(
     }
 }
 
+// Four consecutive elements per lane (16-byte loads, 256 elements per workgroup) when rows of the
+// slab and of the output keep float4 alignment; same per-element summation order as above.
+__global__ __launch_bounds__(1024) void slab_reduce4_kernel(
+    const float* __restrict__ part, int64_t stride, int splits, float* __restrict__ c, int ldc,
+    int NI, int NJ, const float* __restrict__ bpart, float* __restrict__ bias, int main_blocks) {
+    __shared__ float4 sh[16][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= main_blocks) {  // bias partials: scalar, as in slab_reduce_kernel
+        float* shf = reinterpret_cast<float*>(&sh[0][0]);
+        const int64_t e = (int64_t)(blockIdx.x - main_blocks) * 64 + el;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < NI) {
+            int z = g;
+            for (; z + 48 < splits; z += 64) {
+                s0 += bpart[(size_t)z * NI + e];
+                s1 += bpart[(size_t)(z + 16) * NI + e];
+                s2 += bpart[(size_t)(z + 32) * NI + e];
+                s3 += bpart[(size_t)(z + 48) * NI + e];
+            }
+            for (; z < splits; z += 16) s0 += bpart[(size_t)z * NI + e];
+        }
+        shf[g * 64 + el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && e < NI) {
+            float t = shf[el];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) t += shf[q * 64 + el];
+            bias[e] = t;
+        }
+        return;
+    }
+    const int64_t n = (int64_t)NI * NJ;
+    const int64_t e = ((int64_t)blockIdx.x * 64 + el) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+#define MARL_ADD4(d_, v_) \
+    {                     \
+        const float4 t_ = (v_); \
+        d_.x += t_.x;     \
+        d_.y += t_.y;     \
+        d_.z += t_.z;     \
+        d_.w += t_.w;     \
+    }
+    if (e < n) {
+        int z = g;
+        for (; z + 48 < splits; z += 64) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)z * stride + e);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(z + 16) * stride + e);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(z + 32) * stride + e);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(z + 48) * stride + e);
+            MARL_ADD4(s0, v0) MARL_ADD4(s1, v1) MARL_ADD4(s2, v2) MARL_ADD4(s3, v3)
+        }
+        for (; z < splits; z += 16) MARL_ADD4(s0, *reinterpret_cast<const float4*>(part + (size_t)z * stride + e))
+    }
+#undef MARL_ADD4
+    sh[g][el] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                            (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (g == 0 && e < n) {
+        float4 t = sh[0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float4 u = sh[q][el];
+            t.x += u.x;
+            t.y += u.y;
+            t.z += u.z;
+            t.w += u.w;
+        }
+        const int i = (int)(e / NJ), j = (int)(e - (int64_t)i * NJ);  // NJ % 4 == 0: one row
+        *reinterpret_cast<float4*>(c + (size_t)i * ldc + j) = t;
+    }
+}
+
 int launch_slab_reduce(const float* part, int64_t stride, int splits, float* c, int ldc, int ni,
                        int nj, const float* bpart, float* bias, hipStream_t st) {
+    if ((nj & 3) == 0 && (stride & 3) == 0 && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(part) |
+                                                                  reinterpret_cast<uintptr_t>(c)) & 15) == 0) {
+        const int main_blocks = (int)cdiv((int64_t)ni * nj, 256);
+        const int extra = (bpart && bias) ? (int)cdiv(ni, 64) : 0;
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)(main_blocks + extra)), dim3(1024), 0, st, part,
+                           stride, splits, c, ldc, ni, nj, bpart, bias, main_blocks);
+        MARL_LAUNCH_CHECK();
+        return MARL_OK;
+    }
     const int main_blocks = (int)cdiv((int64_t)ni * nj, 64);
     const int extra = (bpart && bias) ? (int)cdiv(ni, 64) : 0;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(main_blocks + extra)), dim3(1024), 0, st,
