@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
                           (grp * BM + wm * (BM / WM) + frag_row) * LDS_K + frag_k;         \
         const float* Bs = smem + (buf_) * BUF + GROUPS * BM * LDS_K +                      \
                           (wn * (BN / WN) + frag_row) * LDS_K + frag_k;                    \
+        if (batch.prio) __builtin_amdgcn_s_setprio(1);                                     \
         _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                            \
             float4 a4[TM], b4[TN];                                                         \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
                 b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);    \
             MARL_MFMA_Q(x) MARL_MFMA_Q(y) MARL_MFMA_Q(z) MARL_MFMA_Q(w)                    \
         }                                                                                  \
+        if (batch.prio) __builtin_amdgcn_s_setprio(0);                                     \
     }
 
     const int frag_row = lane & 31;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       int64_t out_split_stride, int NI, int NJ,
                                                       int64_t rows, int64_t rows_per_split,
                                                       float* __restrict__ csum, int gx, int gy,
-                                                      int gz) {
+                                                      int gz, int prio) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_CH = BK * (BM / 4) / 256;
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         if (tile + 1 < T) MARL_TN_LOAD(tile + 1)
         const float* As = smem + buf * BK * (BM + BN) + wm * (BM / WM) + fcol;
         const float* Bs = smem + buf * BK * (BM + BN) + BK * BM + wn * (BN / WN) + fcol;
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float a[TM], b[TN];
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
     }
 #undef MARL_TN_LOAD1
 #undef MARL_TN_LOAD
@@ -883,6 +887,13 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     constexpr size_t lds2 = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
     batch.single_buf = GROUPS == 1 && !LSTM && BM == 128 && tune_get("nt_single", 1);
+    {
+        // s_setprio(1) around the matrix phase: the scheduler prefers the wave that is feeding
+        // the matrix pipe over a co-resident one that is staging (measured: -3 % on the LSTM
+        // launch, nothing on the others).  bit 0: 64-wide plan, 1: 128-wide, 2: LSTM
+        const int m = tune_get("nt_prio", 4);
+        batch.prio = LSTM ? (m >> 2) & 1 : (BM == 64 ? m & 1 : (m >> 1) & 1);
+    }
     const size_t lds = batch.single_buf ? lds2 / 2 : lds2;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, GROUPS>;
     if (lds2 > 64 * 1024) {
@@ -1127,15 +1138,17 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         grid = dim3(grid.x * grid.y * grid.z);
     }
     prof_before(2, st);
+    // s_setprio(1) around the matrix phase (see launch_nt_variant): -3 % on the weight gradients
+    const int tn_prio = tune_get("tn_prio", 1);
     static const int tbk = (getenv("MARL_TN_BK") && atoi(getenv("MARL_TN_BK")) == 16) ? 16 : 32;
 #define MARL_TN_LAUNCH(BM_, BK_)                                                               \
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, 2, 2, BK_>), grid, dim3(256),                 \
                        (size_t)2 * BK_ * 2 * BM_ * sizeof(float), st, a, lda, b, ldb, out, ldo, \
-                       stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz)
+                       stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz, tn_prio)
     if (p.bm == 128 && tbk == 32 && tune_get("tn_bufs", 1) == 1)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256),
                            (size_t)32 * 2 * 128 * sizeof(float), st, a, lda, b, ldb, out, ldo, stride, ni, nj,
-                           rows, p.rows_per_split, csum, gx, gy, gz);
+                           rows, p.rows_per_split, csum, gx, gy, gz, tn_prio);
     else if (p.bm == 128 && tbk == 32)
         MARL_TN_LAUNCH(128, 32);
     else if (p.bm == 128)
