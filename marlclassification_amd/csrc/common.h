@@ -92,7 +92,6 @@ struct GemmBatch {
     int gx, gy;   // logical tile grid (row blocks, column blocks); filled by the launcher
     int xcd_map;  // 1: 1-D launch with the XCD-aware tile order below
     int single_buf;  // 1: one LDS stage (filled by the launcher)
-    int prio;
 };
 
 // Tile order for tiled kernels whose neighbouring tiles share operand panels.  Workgroup b of

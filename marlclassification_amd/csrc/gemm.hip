@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
                           (grp * BM + wm * (BM / WM) + frag_row) * LDS_K + frag_k;         \
         const float* Bs = smem + (buf_) * BUF + GROUPS * BM * LDS_K +                      \
                           (wn * (BN / WN) + frag_row) * LDS_K + frag_k;                    \
-        if (batch.prio) __builtin_amdgcn_s_setprio(1);                                     \
+        if (LSTM) __builtin_amdgcn_s_setprio(1); /* compile-time: see launch_nt_variant */ \
         _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                            \
             float4 a4[TM], b4[TN];                                                         \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
                 b4[j] = *reinterpret_cast<const float4*>(Bs + j * 32 * LDS_K + kk * 8);    \
             MARL_MFMA_Q(x) MARL_MFMA_Q(y) MARL_MFMA_Q(z) MARL_MFMA_Q(w)                    \
         }                                                                                  \
-        if (batch.prio) __builtin_amdgcn_s_setprio(0);                                     \
+        if (LSTM) __builtin_amdgcn_s_setprio(0);                                           \
     }
 
     const int frag_row = lane & 31;
@@ -887,13 +887,10 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     constexpr size_t lds2 = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
     batch.single_buf = GROUPS == 1 && !LSTM && BM == 128 && tune_get("nt_single", 1);
-    {
-        // s_setprio(1) around the matrix phase: the scheduler prefers the wave that is feeding
-        // the matrix pipe over a co-resident one that is staging (measured: -3 % on the LSTM
-        // launch, nothing on the others).  bit 0: 64-wide plan, 1: 128-wide, 2: LSTM
-        const int m = tune_get("nt_prio", 4);
-        batch.prio = LSTM ? (m >> 2) & 1 : (BM == 64 ? m & 1 : (m >> 1) & 1);
-    }
+    // (LSTM instantiation: s_setprio(1) around the matrix phase - the scheduler prefers the wave
+    // that is feeding the matrix pipe over a co-resident one that is staging: -3 % on the launch.
+    // Compile-time only: even a never-taken run-time branch around the cluster cost the other
+    // plans 3-4 %, it splits the block in which the compiler interleaves LDS reads and MFMAs.)
     const size_t lds = batch.single_buf ? lds2 / 2 : lds2;
     auto kern = gemm_nt_kernel<BM, BN, WM, WN, LSTM, GROUPS>;
     if (lds2 > 64 * 1024) {
@@ -1138,7 +1135,9 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         grid = dim3(grid.x * grid.y * grid.z);
     }
     prof_before(2, st);
-    // s_setprio(1) around the matrix phase (see launch_nt_variant): -3 % on the weight gradients
+    // s_setprio(1) around the matrix phase (see launch_nt_variant): -3 % on the weight gradients.
+    // (Kept behind this run-time flag on purpose: the unconditional form compiles to a 20 % SLOWER
+    // loop - measured 307 vs 254 us - the branch changes how hipcc schedules the cluster.)
     const int tn_prio = tune_get("tn_prio", 1);
     static const int tbk = (getenv("MARL_TN_BK") && atoi(getenv("MARL_TN_BK")) == 16) ? 16 : 32;
 #define MARL_TN_LAUNCH(BM_, BK_)                                                               \
