@@ -451,6 +451,7 @@ struct PanelBwdProb {
     int has_cellb;
     LstmBwdArgs cellb;
     int off_e, off_prm, off_colp, off_part, off_rowmap;  // LDS float offsets (filled by the launcher)
+    int tail_lds;  // 1: the final dX is finished row-wise from an LDS panel (filled by the launcher)
     // optional: extra workgroups behind the panel ones run one LSTM cell's elementwise backward
     // (an independent memory-bound kernel riding along with this latency-bound one)
     int has_cell, panel_blocks;

@@ -538,7 +538,7 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
 constexpr int kBwdMaxCols = kPanelMaxCols;  // columns per lane in the row pass: widths up to 384
 
 template <bool CELL>
-__global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
+__global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (CELL && (int)blockIdx.x >= P.panel_blocks) {
         lstm_cell_bwd_elem(P.cell, P.cell_rows,
@@ -805,7 +805,9 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
                         const int lr = 4 * quad + r;
                         const int row = rw[r];
                         const float v = col < nout ? acc[t][r] : 0.f;
-                        if (last) {
+                        if (last && P.tail_lds) {  // final dX through LDS: finished row-wise below
+                            if (col < o16) E[lr * es + col] = v;
+                        } else if (last) {
                             if (col < nout && row >= 0) {
                                 float* o = P.dx + (size_t)row * P.lddx + col;
                                 const float tot = P.accumulate ? *o + v : v;
@@ -820,6 +822,80 @@ __global__ __launch_bounds__(768) void panel_bwd_kernel(const PanelBwdProb P) {
             }
             lds_barrier();
         }
+        if (last && P.tail_lds) {
+            // Final dX (+ the belief cell's elementwise backward) ROW-wise from the LDS panel: four
+            // consecutive columns per thread, 16-byte loads of everything two items need before
+            // the first store.  In the accumulator layout the same work is eight scattered
+            // elements per lane whose stores keep the next element's loads from being issued
+            // (in-kernel timestamps: 20 us of the 46 us chain).
+            const LstmBwdArgs& Cb = P.cellb;
+            const int c4n = nout >> 2, items = kPanelRows * c4n, cn = Cb.n;
+            // (one item per pass: two in flight need 162 registers and then the riding-along cell
+            // workgroups no longer fit beside a panel workgroup)
+            constexpr int kIt = 1;
+            for (int base = 0; base < items; base += kIt * (int)blockDim.x) {
+                float4 ov[kIt], gi[kIt], gf[kIt], gg[kIt], go[kIt], cnew[kIt], cprev[kIt], dcv[kIt];
+                int rowi[kIt], coli[kIt], lri[kIt];
+#pragma unroll
+                for (int k = 0; k < kIt; ++k) {
+                    const int i = base + tid + k * (int)blockDim.x;
+                    const int lr = i < items ? i / c4n : 0;
+                    const int c = i < items ? (i - lr * c4n) * 4 : 0;
+                    const int row = i < items ? rowmap[lr] : -1;
+                    const size_t rr = row < 0 ? 0 : (size_t)row;
+                    rowi[k] = row;
+                    coli[k] = c;
+                    lri[k] = lr;
+                    ov[k] = P.accumulate ? *reinterpret_cast<const float4*>(P.dx + rr * P.lddx + c)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (P.has_cellb) {
+                        const float* g = Cb.gates + rr * Cb.ldg + c;
+                        gi[k] = *reinterpret_cast<const float4*>(g);
+                        gf[k] = *reinterpret_cast<const float4*>(g + cn);
+                        gg[k] = *reinterpret_cast<const float4*>(g + 2 * cn);
+                        go[k] = *reinterpret_cast<const float4*>(g + 3 * cn);
+                        cnew[k] = *reinterpret_cast<const float4*>(Cb.c_new + rr * Cb.ldc + c);
+                        cprev[k] = *reinterpret_cast<const float4*>(Cb.c_prev + rr * Cb.ldc + c);
+                        dcv[k] = *reinterpret_cast<const float4*>(Cb.dc + rr * Cb.lddc + c);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kIt; ++k) {
+                    if (rowi[k] < 0) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(E + lri[k] * es + coli[k]);
+                    const float tot[4] = {ov[k].x + v.x, ov[k].y + v.y, ov[k].z + v.z, ov[k].w + v.w};
+                    *reinterpret_cast<float4*>(P.dx + (size_t)rowi[k] * P.lddx + coli[k]) =
+                        make_float4(tot[0], tot[1], tot[2], tot[3]);
+                    if (P.has_cellb) {  // lstm_cell_bwd_at() on four consecutive units
+                        const float gi_[4] = {gi[k].x, gi[k].y, gi[k].z, gi[k].w};
+                        const float gf_[4] = {gf[k].x, gf[k].y, gf[k].z, gf[k].w};
+                        const float gg_[4] = {gg[k].x, gg[k].y, gg[k].z, gg[k].w};
+                        const float go_[4] = {go[k].x, go[k].y, go[k].z, go[k].w};
+                        const float cn_[4] = {cnew[k].x, cnew[k].y, cnew[k].z, cnew[k].w};
+                        const float cp_[4] = {cprev[k].x, cprev[k].y, cprev[k].z, cprev[k].w};
+                        const float dc_[4] = {dcv[k].x, dcv[k].y, dcv[k].z, dcv[k].w};
+                        float o0[4], o1[4], o2[4], o3[4], o4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float tc = tanhf(cn_[q]);
+                            const float d = tot[q] * go_[q] * (1.0f - tc * tc) + dc_[q];
+                            o0[q] = d * gg_[q] * gi_[q] * (1.0f - gi_[q]);
+                            o1[q] = d * cp_[q] * gf_[q] * (1.0f - gf_[q]);
+                            o2[q] = d * gi_[q] * (1.0f - gg_[q] * gg_[q]);
+                            o3[q] = tot[q] * tc * go_[q] * (1.0f - go_[q]);
+                            o4[q] = d * gf_[q];
+                        }
+                        float* g = Cb.gates + (size_t)rowi[k] * Cb.ldg + coli[k];
+                        *reinterpret_cast<float4*>(g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                        *reinterpret_cast<float4*>(g + cn) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                        *reinterpret_cast<float4*>(g + 2 * cn) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                        *reinterpret_cast<float4*>(g + 3 * cn) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+                        *reinterpret_cast<float4*>(Cb.dc + (size_t)rowi[k] * Cb.lddc + coli[k]) =
+                            make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+                }
+            }
+        }
         float* tmp = D;
         D = E;
         E = tmp;
@@ -831,6 +907,14 @@ int panel_chain_blocks(int na, int nb) { return na >= 1 && na <= kPanelRows ? (i
 
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     int waves = 8, pmax = 0, nmax = 0, prm = 0;
+    // the last layer's dX goes through LDS and is finished row-wise (16-byte accesses) when its
+    // rows keep float4 alignment
+    const PanelBwdLayer& Ll = p.layer[p.nlayers - 1];
+    const bool tail_lds = (Ll.k_in & 3) == 0 && (p.lddx & 3) == 0 &&
+                          (!p.has_cellb || ((p.cellb.n & 3) == 0 && (p.cellb.ldg & 3) == 0 && (p.cellb.ldc & 3) == 0 &&
+                                            (p.cellb.lddc & 3) == 0 && p.cellb.n == Ll.k_in)) &&
+                          tune_get("panel_tail_lds", 1) != 0;
+    p.tail_lds = tail_lds ? 1 : 0;
     for (int l = 0; l < p.nlayers; ++l) {
         const PanelBwdLayer& L = p.layer[l];
         if (L.n > 64 * kBwdMaxCols) {
@@ -842,7 +926,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
         waves = w > waves ? w : waves;
         nmax = L.n > nmax ? L.n : nmax;
         pmax = panel_stride(L.n) > pmax ? panel_stride(L.n) : pmax;
-        if (l + 1 < p.nlayers && panel_stride(L.k_in) > pmax) pmax = panel_stride(L.k_in);
+        if ((l + 1 < p.nlayers || tail_lds) && panel_stride(L.k_in) > pmax) pmax = panel_stride(L.k_in);
         prm += 2 * L.n;
     }
     if (waves > kPanelMaxWaves) waves = kPanelMaxWaves;
