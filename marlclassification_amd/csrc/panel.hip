@@ -334,12 +334,10 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         panel_ksum(acc, part, nt, ks, j, s, lane, active);
         MARL_TS();
 
-        // z = acc + bias -> output panel in LDS (and global, kept for backward)
+        // z = acc + bias -> output panel in LDS (its copy kept for backward is written row-wise,
+        // coalesced, by the LayerNorm pass below instead of as 64-byte pieces from this layout)
         const int ys = panel_stride(n), n16 = (n + 15) & ~15;
         if (active && s == 0) {
-            int rw[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rw[r] = Lr.z ? rowmap[4 * quad + r] : -1;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int col = j * 32 + 16 * t + l16;
@@ -350,7 +348,6 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                     const int lr = 4 * quad + r;
                     const float zv = cv ? acc[t][r] + bv : 0.f;
                     if (col < n16) outp[lr * ys + col] = zv;
-                    if (cv && rw[r] >= 0) Lr.z[(size_t)rw[r] * Lr.ldz + col] = zv;
                 }
             }
         }
@@ -375,6 +372,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                 const int lr = wave + i * nwaves;
                 if (lr < kPanelRows) {  // wave-uniform
                     float* zr = outp + lr * ys;
+                    const int row = rowmap[lr];
                     float v[kPanelMaxCols];
                     float sm = 0.f;
 #pragma unroll
@@ -382,6 +380,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                         const int c = lane + 64 * u;
                         v[u] = c < n ? zr[c] : 0.f;
                         sm += v[u];
+                        if (Lr.z && row >= 0 && c < n) Lr.z[(size_t)row * Lr.ldz + c] = v[u];
                     }
                     const float mean = wave_sum(sm) * inv_n;
                     float q = 0.f;
@@ -393,7 +392,6 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                         q += d * d;
                     }
                     const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + 1e-5f);
-                    const int row = rowmap[lr];
                     float* arow = Lr.a + (size_t)(row < 0 ? 0 : row) * Lr.lda;
 #pragma unroll
                     for (int u = 0; u < kPanelMaxCols; ++u) {
