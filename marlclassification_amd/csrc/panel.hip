@@ -565,6 +565,26 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
     }
     lds_barrier();
 
+    // The saved pre-LayerNorm rows (and statistics) of a layer are requested one layer ahead: the
+    // two rows of this wave for layer l + 1 fly while layer l's dX product runs.  Unconditional
+    // loads (padding rows read row 0) so that no wait is widened by a branch.
+    float zpre[2][kBwdMaxCols], mpre[2], rpre[2];
+    auto zfetch = [&](const PanelBwdLayer& L) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = wave + i * nwaves;
+            const int row = lr < kPanelRows ? rowmap[lr] : -1;
+            const size_t rr = row < 0 ? 0 : (size_t)row;
+            mpre[i] = L.stats[rr * 2];
+            rpre[i] = L.stats[rr * 2 + 1];
+#pragma unroll
+            for (int u = 0; u < kBwdMaxCols; ++u) {
+                const int c = lane + 64 * u;
+                zpre[i][u] = c < L.n ? L.z[rr * L.ldz + c] : 0.f;
+            }
+        }
+    };
+    zfetch(P.layer[0]);  // first: in flight behind the parameter and gradient-panel loads below
     // LayerNorm affine parameters of every layer -> LDS; d(a_last) panel -> D
     {
         // (all layers' vectors requested before anything is waited for; n <= 384 <= threads)
@@ -633,26 +653,6 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
     }
     lds_barrier();
 
-    // The saved pre-LayerNorm rows (and statistics) of a layer are requested one layer ahead: the
-    // two rows of this wave for layer l + 1 fly while layer l's dX product runs.  Unconditional
-    // loads (padding rows read row 0) so that no wait is widened by a branch.
-    float zpre[2][kBwdMaxCols], mpre[2], rpre[2];
-    auto zfetch = [&](const PanelBwdLayer& L) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int lr = wave + i * nwaves;
-            const int row = lr < kPanelRows ? rowmap[lr] : -1;
-            const size_t rr = row < 0 ? 0 : (size_t)row;
-            mpre[i] = L.stats[rr * 2];
-            rpre[i] = L.stats[rr * 2 + 1];
-#pragma unroll
-            for (int u = 0; u < kBwdMaxCols; ++u) {
-                const int c = lane + 64 * u;
-                zpre[i][u] = c < L.n ? L.z[rr * L.ldz + c] : 0.f;
-            }
-        }
-    };
-    zfetch(P.layer[0]);
     int prm_off = 0;
     for (int l = 0; l < P.nlayers; ++l) {
         const PanelBwdLayer Lr = P.layer[l];  // by value: no scalar re-loads inside the loops
