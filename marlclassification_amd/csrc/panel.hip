@@ -908,10 +908,13 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     // the last layer's dX goes through LDS and is finished row-wise (16-byte accesses) when its
     // rows keep float4 alignment
     const PanelBwdLayer& Ll = p.layer[p.nlayers - 1];
-    const bool tail_lds = (Ll.k_in & 3) == 0 && (p.lddx & 3) == 0 &&
-                          (!p.has_cellb || ((p.cellb.n & 3) == 0 && (p.cellb.ldg & 3) == 0 && (p.cellb.ldc & 3) == 0 &&
-                                            (p.cellb.lddc & 3) == 0 && p.cellb.n == Ll.k_in)) &&
-                          tune_get("panel_tail_lds", 1) != 0;
+    bool tail_lds = (Ll.k_in & 3) == 0 && (p.lddx & 3) == 0 &&
+                    (!p.has_cellb || ((p.cellb.n & 3) == 0 && (p.cellb.ldg & 3) == 0 && (p.cellb.ldc & 3) == 0 &&
+                                      (p.cellb.lddc & 3) == 0 && p.cellb.n == Ll.k_in)) &&
+                    tune_get("panel_tail_lds", 1) != 0;
+plan:  // (second pass without the LDS tail when the extra output panel does not fit)
+    waves = 8;
+    pmax = nmax = prm = 0;
     p.tail_lds = tail_lds ? 1 : 0;
     for (int l = 0; l < p.nlayers; ++l) {
         const PanelBwdLayer& L = p.layer[l];
@@ -938,6 +941,10 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
                          !panel_chain_supported(p.g_na, p.layer[p.agg_at].n, 256))) {
         set_error("panel backward: in-panel message mean outside its range");
         return MARL_ELIMIT;
+    }
+    if (lds > kPanelMaxLds && tail_lds) {
+        tail_lds = false;
+        goto plan;
     }
     if (lds > kPanelMaxLds) {
         set_error("panel backward: shape outside its range");

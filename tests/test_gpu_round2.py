@@ -158,6 +158,20 @@ def test_worldstrat_five_layer_cnn_matches_oracle(device):
     _check_against_oracle(eng, cfg, device, params, img, y, inp, ns)
 
 
+# ---- the published checkpoints' widths ("nothing may be hard-coded to the README dims") --
+@pytest.mark.parametrize("dims", [(512, 512, 384, 384), (768, 512, 768, 758)])
+def test_published_checkpoint_widths_match_oracle(device, dims):
+    """resources/trained_models use n_b = 512 / 768 and head widths up to 1024: the wide belief
+    state runs through the chained panel kernels (LDS tail of the backward chain, or its fallback
+    when the extra panel does not fit), the 758-wide policy layer through the unfused path."""
+    n_b, n_a, nlb, nla = dims
+    cfg = mo.OracleConfig("resisc45", 12, n_b, n_a, 64, 96, 16, 45, nlb, nla)
+    na, nb, ns, shape = 4, 3, 3, (3, 40, 48)
+    params, img, y, inp = _oracle_case(cfg, na, nb, ns, shape, seed=33)
+    eng = _engine(cfg, device, na, nb, ns, shape, params)
+    _check_against_oracle(eng, cfg, device, params, img, y, inp, ns)
+
+
 # ---- (f) uint8 images: ToTensor inside the kernels vs the oracle on x / 255 -------------------
 def test_uint8_episode_matches_oracle_on_scaled_images(device):
     g = Golden("g1_conftest")
