@@ -67,6 +67,10 @@ struct GemmSeg {
     const float* a;
     const float* b;
     int lda, ldb, k;
+    // filled by the bf16x6 launcher when b is a registered weight matrix: its pre-split image
+    // [row][k / 32][plane][32] bf16 and the number of 32-deep K tiles per row
+    const void* b3;
+    int kt3;
 };
 
 struct GemmProb {
@@ -92,6 +96,9 @@ struct GemmBatch {
     int gx, gy;   // logical tile grid (row blocks, column blocks); filled by the launcher
     int xcd_map;  // 1: 1-D launch with the XCD-aware tile order below
     int single_buf;  // 1: one LDS stage (filled by the launcher)
+#ifdef MARL_KERNEL_TS
+    long long* ts;  // phase timestamps of one workgroup (debug builds only)
+#endif
 };
 
 // Tile order for tiled kernels whose neighbouring tiles share operand panels.  Workgroup b of
@@ -118,6 +125,34 @@ void gemm_add_seg(GemmProb& p, const float* a, int lda, const float* b, int ldb,
 int launch_gemm_nt(const GemmBatch& batch, hipStream_t st);
 // LSTM cell: gates = seg products + bias over 4*n_units rows of B, then the cell update.
 int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st);
+
+// bf16x6 forms of the three matrix kernels (gemm_split.hip): fp32 operands split into three bf16
+// terms while they are staged, six bf16 MFMA products per fp32 product, fp32 accumulation.
+// split_mode(): knob "mfma_split" (default 1); 0 = the exact-fp32 v_mfma_f32_32x32x2_f32 kernels.
+int split_mode();
+// Pre-split images of the weight matrices (built by marl_pack_weights next to their fp32 copies):
+// a matrix [rows][ld] fp32 with k valid columns -> [rows][ceil(k / 32)][3][32] bf16, zero-padded.
+size_t split_image_floats(int rows, int k);  // size of an image in units of 4 bytes
+struct SplitDesc {
+    const float* src;  // [rows][ld]
+    void* dst;
+    int rows, k, ld, kt;
+};
+constexpr int kMaxSplitDesc = 64;
+struct SplitBatch {
+    SplitDesc d[kMaxSplitDesc];
+    int count;
+};
+int launch_split_weights(const SplitBatch& b, hipStream_t st);
+// host-side table fp32 copy -> image, rebuilt by every entry point that lays out the weights
+// workspace; the launchers look the B operands of a product up in it
+void split_registry_reset();
+void split_registry_add(const float* base, int rows, int ld, int k, const void* image);
+int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st);
+int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStream_t st);
+int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
+                         int64_t stride, int ni, int nj, int64_t rows, int64_t rows_per_split,
+                         float* csum, dim3 grid, int gx, int gy, int gz, hipStream_t st);
 
 // per-launch HIP-event timing of one kernel class (see marl_profile_begin); no-ops when off
 constexpr int kProfClasses = 6;

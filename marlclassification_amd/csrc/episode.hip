@@ -194,6 +194,7 @@ struct WLayout {
     size_t wt[MARL_NPARAMS];  // transposed copy [k, p4(n)]
     int ldt[MARL_NPARAMS];
     size_t gp[MARL_NPARAMS];  // packed gradient (same shape as wp)
+    size_t wp3[MARL_NPARAMS], wt3[MARL_NPARAMS];  // bf16x3 images of wp / wt (gemm_split.hip)
     size_t bsum_b, bsum_a;    // b_ih + b_hh
     size_t total;
 };
@@ -202,7 +203,7 @@ static void make_wlayout(const Dims& d, WLayout& w) {
     Bump b;
     for (int i = 0; i < MARL_NPARAMS; ++i) {
         const ParamMeta m = param_meta(d, i);
-        w.wp[i] = w.wt[i] = w.gp[i] = 0;
+        w.wp[i] = w.wt[i] = w.gp[i] = w.wp3[i] = w.wt3[i] = 0;
         w.ldp[i] = w.ldt[i] = 0;
         if (m.kind == PK_MATRIX || m.kind == PK_CONV) {
             w.ldp[i] = p4(m.k);
@@ -210,6 +211,10 @@ static void make_wlayout(const Dims& d, WLayout& w) {
             w.ldt[i] = p4(m.n);
             w.wt[i] = b.take((size_t)m.k * w.ldt[i]);
             w.gp[i] = b.take((size_t)m.n * w.ldp[i]);
+            if (m.kind == PK_MATRIX) {
+                w.wp3[i] = b.take(split_image_floats(m.n, m.k));
+                w.wt3[i] = b.take(split_image_floats(m.k, m.n));
+            }
         } else if (m.kind == PK_VEC) {
             w.ldp[i] = m.n;
             w.wp[i] = b.take((size_t)m.n);
@@ -492,6 +497,8 @@ struct Ctx {
     float* DHCs(int t) const { return E + e.DHC + (size_t)t * d.R * d.ld_na; }
 };
 
+static void register_split_images(const Dims& d, const WLayout& w, const float* W);
+
 static int make_ctx(const marl_config* cfg, const void* wws, void* ews, int train, void* stream,
                     Ctx& c) {
     MARL_TRY(make_dims(cfg, c.d));
@@ -509,6 +516,7 @@ static int make_ctx(const marl_config* cfg, const void* wws, void* ews, int trai
         set_error("workspaces must be 256-byte aligned");
         return MARL_EINVAL;
     }
+    register_split_images(c.d, c.w, c.W);
     return MARL_OK;
 }
 
@@ -980,7 +988,28 @@ static int pack_weights(const Dims& d, const WLayout& w, const float* const* par
     q.push(perm(params[MARL_P_LA_BIH], W + w.bsum_a, 1, 4 * d.n_a, 4 * d.n_a, 1, 0, 0, 1, 1, 0,
                 params[MARL_P_LA_BHH]));
     q.flush();
-    return q.rc;
+    MARL_TRY(q.rc);
+    // bf16x3 images of every matrix copy (read back from the fp32 copies just written)
+    SplitBatch sb{};
+    sb.count = 0;
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        if (m.kind != PK_MATRIX) continue;
+        sb.d[sb.count++] = SplitDesc{W + w.wp[i], W + w.wp3[i], m.n, m.k, w.ldp[i], (m.k + 31) / 32};
+        sb.d[sb.count++] = SplitDesc{W + w.wt[i], W + w.wt3[i], m.k, m.n, w.ldt[i], (m.n + 31) / 32};
+    }
+    return launch_split_weights(sb, st);
+}
+
+// tells the bf16x6 launchers where the image of each fp32 weight copy lives
+static void register_split_images(const Dims& d, const WLayout& w, const float* W) {
+    split_registry_reset();
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        if (m.kind != PK_MATRIX) continue;
+        split_registry_add(W + w.wp[i], m.n, w.ldp[i], m.k, W + w.wp3[i]);
+        split_registry_add(W + w.wt[i], m.k, w.ldt[i], m.n, W + w.wt3[i]);
+    }
 }
 
 static int unpack_grads(const Ctx& c, float* const* grads) {

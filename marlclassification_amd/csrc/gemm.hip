@@ -969,7 +969,9 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
                     batch.p[i].nseg > 1 ? batch.p[i].seg[1].k : 0, batch.p[i].accumulate,
                     batch.p[i].bias != nullptr, batch.p[i].seg[0].lda, batch.p[i].ldc);
     prof_before(1, st);
-    if (blocks128 >= tune_get("nt_min_blocks128", 256) && max_n >= 96) {
+    if (split_mode()) {
+        MARL_TRY(launch_gemm_nt_split(batch, max_m, max_n, blocks128, st));
+    } else if (blocks128 >= tune_get("nt_min_blocks128", 256) && max_n >= 96) {
         const int g = gemm_groups();
         dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         if (g == 2)
@@ -1051,7 +1053,9 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
     const int g = gemm_groups();
     dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
     prof_before(0, st);
-    if (g == 2)
+    if (split_mode())
+        MARL_TRY(launch_gemm_lstm_split(batch, max_m, max_n, st));
+    else if (g == 2)
         MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 2>(grid, batch, st)));
     else
         MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 1>(grid, batch, st)));
@@ -1072,7 +1076,9 @@ static TnPlan tn_plan(int ni, int nj, int64_t rows) {
     // target turns into hundreds of row slabs and the slab reduction costs more than the product
     p.bm = (ni >= 96 && nj >= 96 && cdiv(ni, 128) * cdiv(nj, 128) >= 4) ? 128 : 64;
     const int64_t tiles = cdiv(ni, p.bm) * cdiv(nj, p.bm);
-    int64_t s = cdiv(tune_get("tn_target_wgs", 768), tiles);
+    // (the bf16x6 kernel keeps two workgroups per CU resident, the fp32 one three)
+    const int target = (p.bm == 128 && split_mode()) ? tune_get("tn_split_wgs", 512) : tune_get("tn_target_wgs", 768);
+    int64_t s = cdiv(target, tiles);
     const int64_t max_s = cdiv(rows, 4 * BK);  // at least 4 K tiles per split
     if (s > max_s) s = max_s;
     if (s > 512) s = 512;
@@ -1144,7 +1150,10 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, 2, 2, BK_>), grid, dim3(256),                 \
                        (size_t)2 * BK_ * 2 * BM_ * sizeof(float), st, a, lda, b, ldb, out, ldo, \
                        stride, ni, nj, rows, p.rows_per_split, csum, gx, gy, gz, tn_prio)
-    if (p.bm == 128 && tbk == 32 && tune_get("tn_bufs", 1) == 1)
+    if (p.bm == 128 && split_mode())
+        MARL_TRY(launch_gemm_tn_split(a, lda, b, ldb, out, ldo, stride, ni, nj, rows, p.rows_per_split, csum,
+                                      grid, gx, gy, gz, st));
+    else if (p.bm == 128 && tbk == 32 && tune_get("tn_bufs", 1) == 1)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256),
                            (size_t)32 * 2 * 128 * sizeof(float), st, a, lda, b, ldb, out, ldo, stride, ni, nj,
                            rows, p.rows_per_split, csum, gx, gy, gz, tn_prio);

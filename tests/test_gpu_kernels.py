@@ -22,6 +22,16 @@ def _p4(x):
     return (x + 3) & ~3
 
 
+@pytest.fixture(params=[1, 0], ids=["bf16x6", "f32mfma"])
+def mfma_split(request):
+    """Both forms of the matrix kernels: 1 = fp32 operands split into three bf16 terms, six bf16
+    MFMA products (gemm_split.hip, the default); 0 = v_mfma_f32_32x32x2_f32 (gemm.hip)."""
+    lib, check = _lib()
+    check(lib.marl_tune(b"mfma_split", request.param))
+    yield request.param
+    check(lib.marl_tune(b"mfma_split", 1))
+
+
 def _padded(t, ld):
     out = th.zeros(t.shape[0], ld, device=t.device)
     out[:, : t.shape[1]] = t
@@ -32,7 +42,7 @@ def _padded(t, ld):
                                    (4096, 512, 368), (3000, 130, 7), (300, 2048, 624),
                                    (32768 + 77, 368, 200)])  # last: many row blocks, ragged M and N
 @pytest.mark.parametrize("acc", [0, 1])
-def test_gemm_nt(device, m, n, k, acc):
+def test_gemm_nt(device, mfma_split, m, n, k, acc):
     lib, check = _lib()
     g = th.Generator().manual_seed(m * 7 + n * 3 + k)
     a = th.randn(m, k, generator=g)
@@ -54,7 +64,7 @@ def test_gemm_nt(device, m, n, k, acc):
     assert th.equal(cd[:, n:].cpu(), th.zeros(m, ldc - n)), "wrote outside [M, N]"
 
 
-def test_gemm_nt_is_transpose_detecting(device):
+def test_gemm_nt_is_transpose_detecting(device, mfma_split):
     # asymmetric operands: A = identity-like rows selects rows of B exactly
     lib, check = _lib()
     m, n, k = 64, 96, 64
@@ -69,8 +79,9 @@ def test_gemm_nt_is_transpose_detecting(device):
 
 
 @pytest.mark.parametrize("rows,ni,nj", [(665, 92, 183), (5000, 16, 27), (20000, 200, 130),
-                                        (33, 1, 24), (70000, 8, 9), (4096, 1024, 368)])
-def test_gemm_tn(device, rows, ni, nj):
+                                        (33, 1, 24), (70000, 8, 9), (4096, 1024, 368),
+                                        (9001, 300, 257), (65536, 384, 256)])
+def test_gemm_tn(device, mfma_split, rows, ni, nj):
     lib, check = _lib()
     g = th.Generator().manual_seed(rows + ni + nj)
     a = th.randn(rows, ni, generator=g)
