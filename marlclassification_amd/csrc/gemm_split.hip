@@ -33,13 +33,18 @@ namespace {
 
 constexpr int SK = 32;     // K depth of a staged tile (two 16-deep MFMA steps)
 constexpr int SROW = 80;   // LDS bytes per tile row: 32 bf16 + 16 B pad
+constexpr int plane_bytes(int rows) { return rows * SROW; }
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
 }
+// (sched_barrier: nothing - in particular no matrix instruction, which touches registers only -
+// may be scheduled across the barrier: each tile body is one scheduling region)
 __device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // two fp32 values -> one dword (x low half, y high half) per bf16 term
@@ -65,63 +70,100 @@ __device__ __forceinline__ void split_store4(char* dst, int plane, float a, floa
 
 // Matrix phase of one staged tile.  al / bl: this lane's fragment address in plane 0 of the A / B
 // image (row = tile row of the wave + lane % 32, k = (lane / 32) * 8); planes APL / BPL bytes apart.
-// All fragments of a 16-deep step are read first, then the MFMAs walk the accumulators round
-// robin, smallest terms first.
+// All 12 + 12 fragment reads of the tile are issued up front (the wave has the registers), the
+// MFMAs walk the accumulators round robin, smallest terms first.
+template <int TM, int TN>
+struct SplitFrags {
+    bf16x8 a[3][TM], b[3][TN];
+};
 template <int TM, int TN, int APL, int BPL>
-__device__ __forceinline__ void split_compute(const char* al, const char* bl, f32x16 (&acc)[TM][TN]) {
-    constexpr int JC = TM >= 2 ? 1 : (TN > 2 ? 2 : TN);  // column tiles per pass (bounds the fragment registers)
+__device__ __forceinline__ void split_read(const char* al, const char* bl, int kk, SplitFrags<TM, TN>& f) {
 #pragma unroll
-    for (int kk = 0; kk < SK / 16; ++kk) {
-        bf16x8 a[3][TM];
+    for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int i = 0; i < TM; ++i)
+            f.a[p][i] = *reinterpret_cast<const bf16x8*>(al + p * APL + i * 32 * SROW + kk * 32);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[p][i] = *reinterpret_cast<const bf16x8*>(al + p * APL + i * 32 * SROW + kk * 32);
-#pragma unroll
-        for (int j0 = 0; j0 < TN; j0 += JC) {
-            bf16x8 b[3][JC];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int j = 0; j < JC; ++j)
-                    b[p][j] = *reinterpret_cast<const bf16x8*>(bl + p * BPL + (j0 + j) * 32 * SROW + kk * 32);
+        for (int j = 0; j < TN; ++j)
+            f.b[p][j] = *reinterpret_cast<const bf16x8*>(bl + p * BPL + j * 32 * SROW + kk * 32);
+    }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void split_mfma(const SplitFrags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
 #define MARL_SPLIT_P(pa_, pb_)                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
-        _Pragma("unroll") for (int j = 0; j < JC; ++j)                                     \
-            acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa_][i], b[pb_][j], acc[i][j0 + j], 0, 0, 0);
-            MARL_SPLIT_P(1, 1) MARL_SPLIT_P(0, 2) MARL_SPLIT_P(2, 0)
-            MARL_SPLIT_P(0, 1) MARL_SPLIT_P(1, 0) MARL_SPLIT_P(0, 0)
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa_][i], f.b[pb_][j], acc[i][j], 0, 0, 0);
+    MARL_SPLIT_P(1, 1) MARL_SPLIT_P(0, 2) MARL_SPLIT_P(2, 0)
+    MARL_SPLIT_P(0, 1) MARL_SPLIT_P(1, 0) MARL_SPLIT_P(0, 0)
 #undef MARL_SPLIT_P
-        }
+}
+template <int TM, int TN, int APL, int BPL>
+__device__ __forceinline__ void split_compute(const char* al, const char* bl, f32x16 (&acc)[TM][TN]) {
+    SplitFrags<TM, TN> f0, f1;
+    split_read<TM, TN, APL, BPL>(al, bl, 0, f0);
+    split_read<TM, TN, APL, BPL>(al, bl, 1, f1);
+    split_mfma<TM, TN>(f0, acc);
+    split_mfma<TM, TN>(f1, acc);
+}
+
+// Issue order of one pipelined tile body (a single scheduling region): the fragment reads and
+// the memory requests first, then every MFMA followed by NV single-issue instructions of the
+// staging arithmetic (they run in the 32-cycle shadow of the matrix instruction) and, every
+// other MFMA, one LDS store.  hipcc by itself emits the staging arithmetic as ONE block in
+// front of 48 back-to-back MFMAs (no overlap at all: 2.1 us per tile instead of 0.8).
+template <int NMFMA, int NV, int NREAD, int NVMEM>
+__device__ __forceinline__ void split_pipeline() {
+    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);   // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);   // VMEM reads
+#pragma unroll
+    for (int m = 0; m < NMFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU
+        if (m & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
     }
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// NT: C[M,N] (+)= sum_s A_s[M,K_s] * B_s[N,K_s]^T + bias, optional LSTM-cell epilogue.
-// 128 x BN tiles, 4 waves; two sets of staging registers keep two K tiles in flight over ONE
-// LDS stage (two workgroups per CU: one stages while the other feeds the matrix pipe).
+// Both kernels are software-pipelined inside ONE wave per SIMD (256 threads, one workgroup per
+// CU, two LDS stages of 60 KB, up to 512 registers): while the 48 MFMAs of tile t run from LDS
+// stage t % 2, the same wave splits tile t + 1 (already in registers) into the other stage and
+// issues the loads of tile t + 3 - the VALU / LDS / memory instructions sit in the 32-cycle
+// shadows of the matrix instructions (tools/ubench_split.hip; MI355X_MICROARCH.md: up to 5
+// single-issue instructions per v_mfma_f32_32x32x16_bf16), one barrier per tile.  Two
+// independent workgroups per CU measured 2x slower per phase (they drift into lockstep), a
+// ping-pong pair of wave groups likewise.
 // ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
+// NT: C[M,N] (+)= sum_s A_s[M,K_s] * B_s[N,K_s]^T + bias, optional LSTM-cell epilogue; 128 x BN tiles.
 // BPRE: the B operands are weights whose bf16x3 image already exists in the weights workspace
 // (split_weights_kernel: [row][k / 32][plane][32] bf16, zero-padded to whole K tiles) - their tiles
-// are copied, not split: the staging arithmetic of the kernel halves.
+// are copied, not split.
+// ---------------------------------------------------------------------------
 template <int BN, bool LSTM, bool BPRE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch batch) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm_nt_split_kernel(const GemmBatch batch) {
     constexpr int BM = 128;
-    constexpr int B3_CH = BN * 12 / 256;       // 16-byte chunks of a pre-split B tile per thread
     constexpr int WM = LSTM ? 4 : 2, WN = LSTM ? 1 : 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KC = SK / 4;                 // float4 chunks per tile row
     constexpr int A_CH = BM * KC / 256;        // 4
     constexpr int B_CH = BN * KC / 256;        // 4 or 2
-    constexpr int APL = BM * SROW, BPL = BN * SROW;
+    constexpr int B3_CH = BN * 12 / 256;       // 16-byte chunks of a pre-split B tile per thread
+    constexpr int APL = plane_bytes(BM), BPL = plane_bytes(BN);
+    constexpr int GSZ = 3 * (APL + BPL);       // LDS bytes of one stage
+    // A pre-split B tile row is 3 planes x 64 bytes: the 256 / BN threads of a row take the
+    // 16-byte columns [h * BH, +BH) of every plane - one global offset and one LDS address per
+    // thread plus immediates cover all of a thread's chunks.
+    constexpr int BR = 256 / BN;   // threads per B row: 2 or 4
+    constexpr int BH = 4 / BR;     // 16-byte columns per thread and plane: 2 or 1
+    static_assert(3 * BH == B3_CH, "chunk count");
     static_assert(!LSTM || BN == 128, "LSTM tile = 4 gates x 32 units");
 
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    char* const As = smem_c;
-    char* const Bs = smem_c + 3 * APL;
 
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (batch.xcd_map) xcd_tile(batch.gx, batch.gy, batch.count, bx, by, bz);
@@ -135,9 +177,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int t0 = (P.seg[0].k + SK - 1) / SK;
-    const int t1 = P.nseg > 1 ? (P.seg[1].k + SK - 1) / SK : 0;
-    const int T = t0 + t1;
+    // the two K segments (LSTM: [u_t | h]); wave-uniform scalar state
+    const int ks0 = P.seg[0].k, ks1 = P.nseg > 1 ? P.seg[1].k : 0;
+    const int t0 = (ks0 + SK - 1) / SK;
+    const int T = t0 + (ks1 + SK - 1) / SK;
+    const int K40 = (ks0 + 3) & ~3, K41 = (ks1 + 3) & ~3;
+    const char* const a0p = reinterpret_cast<const char*>(P.seg[0].a);
+    const char* const a1p = reinterpret_cast<const char*>(P.seg[1].a);
+    const char* const b0p = reinterpret_cast<const char*>(BPRE ? P.seg[0].b3 : (const void*)P.seg[0].b);
+    const char* const b1p = reinterpret_cast<const char*>(BPRE ? P.seg[1].b3 : (const void*)P.seg[1].b);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -148,170 +196,127 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // staging: thread t moves A chunks c = t + 256 i (tile row c / KC, floats [(c % KC) * 4, +4)),
-    // B likewise; address = uniform base (advanced per tile on the scalar unit) + fixed 32-bit
-    // per-thread byte offset.  Rows beyond M / N are clamped (never stored).
+    // fp32 B likewise.  Rows beyond M / N are clamped (never stored).  Byte offsets of both
+    // segments are kept in registers (this kernel has 512 of them).
     const int koff = (tid % KC) * 4;
-    uint32_t aof[A_CH], bof[BPRE ? B3_CH : B_CH];
-    const char* abase = nullptr;
-    const char* bbase = nullptr;
-    int K4cur = 0;
-    auto set_seg_a = [&](int sg) {
+    uint32_t aof0[A_CH], aof1[A_CH], bof0[BPRE ? 1 : B_CH], bof1[BPRE ? 1 : B_CH];
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            int gm = m0 + (tid + 256 * i) / KC;
-            gm = gm < M ? gm : M - 1;
-            aof[i] = ((uint32_t)gm * (uint32_t)P.seg[sg].lda + (uint32_t)koff) * 4u;
-        }
-        abase = reinterpret_cast<const char*>(P.seg[sg].a);
-        K4cur = (P.seg[sg].k + 3) & ~3;
-    };
-    auto set_seg_b = [&](int sg) {
+    for (int i = 0; i < A_CH; ++i) {
+        int r = m0 + (tid + 256 * i) / KC;
+        r = r < M ? r : M - 1;
+        aof0[i] = (uint32_t)r * (uint32_t)P.seg[0].lda * 4u;
+        aof1[i] = (uint32_t)r * (uint32_t)P.seg[1].lda * 4u;
+    }
 #pragma unroll
-        for (int i = 0; i < (BPRE ? B3_CH : B_CH); ++i) {
-            const int c = tid + 256 * i;
-            const int row = BPRE ? c / 12 : c / KC;
-            int gn;
-            if (LSTM) {
-                int unit = n0 + (row & 31);
-                unit = unit < N ? unit : N - 1;
-                gn = (row >> 5) * N + unit;
-            } else {
-                gn = n0 + row;
-                gn = gn < N ? gn : N - 1;
-            }
-            if (BPRE)  // row gn of the image: kt tiles of 192 bytes; chunk c % 12 of the tile
-                bof[i] = (uint32_t)gn * (uint32_t)P.seg[sg].kt3 * 192u + (uint32_t)(c % 12) * 16u;
-            else
-                bof[i] = ((uint32_t)gn * (uint32_t)P.seg[sg].ldb + (uint32_t)koff) * 4u;
+    for (int i = 0; i < (BPRE ? 1 : B_CH); ++i) {
+        const int row = BPRE ? tid / BR : (tid + 256 * i) / KC;
+        int gn;
+        if (LSTM) {
+            int unit = n0 + (row & 31);
+            unit = unit < N ? unit : N - 1;
+            gn = (row >> 5) * N + unit;
+        } else {
+            gn = n0 + row;
+            gn = gn < N ? gn : N - 1;
         }
-        bbase = BPRE ? reinterpret_cast<const char*>(P.seg[sg].b3) : reinterpret_cast<const char*>(P.seg[sg].b);
-    };
+        if (BPRE) {  // row gn of the image: kt tiles of 192 bytes; this thread's byte column
+            bof0[i] = (uint32_t)gn * (uint32_t)P.seg[0].kt3 * 192u + (uint32_t)(tid % BR) * (BH * 16);
+            bof1[i] = (uint32_t)gn * (uint32_t)P.seg[1].kt3 * 192u + (uint32_t)(tid % BR) * (BH * 16);
+        } else {
+            bof0[i] = (uint32_t)gn * (uint32_t)P.seg[0].ldb * 4u;
+            bof1[i] = (uint32_t)gn * (uint32_t)P.seg[1].ldb * 4u;
+        }
+    }
 
-    float4 raX[A_CH], raY[A_CH];
-    float4 rbX[BPRE ? 1 : B_CH], rbY[BPRE ? 1 : B_CH];  // fp32 B: two sets like A
-    u32x4 rb3[BPRE ? B3_CH : 1];                         // pre-split B: ONE set, a tile ahead (L2-resident)
-    float mkX = 1.f, mkY = 1.f;
-    bool maskedX = false, maskedY = false;
-    // UNCONDITIONAL loads (a load behind a branch makes hipcc drain vmcnt): tiles past the end
-    // re-read the last tile; only the last tile of a segment can reach past round4(K) - there
-    // the chunk address is clamped into the row (finite values) and the B side is zero: the
-    // fp32 form is zeroed when it goes to LDS, the pre-split image is zero-padded.
-    // Issue order: the B tile (needed first) before the A tile that stays in flight longer.
-#define MARL_SP_LOADB3(tile_)                                                              \
-    if (BPRE) {                                                                            \
-        const bool live_ = (tile_) < T;                                                    \
-        if (live_ && (tile_) == t0 && t1 > 0) set_seg_b(1);                                \
-        bbase -= live_ ? 0 : 192;                                                          \
-        _Pragma("unroll") for (int i = 0; i < B3_CH; ++i)                                  \
-            rb3[BPRE ? i : 0] = *reinterpret_cast<const u32x4*>(bbase + bof[i]);           \
-        bbase += 192;                                                                      \
-    }
-#define MARL_SP_LOAD(ra_, rb_, mk_, masked_, tile_)                                        \
+    // four sets of staging registers: tile u + 4 is requested while tile u is multiplied (three
+    // tile times of latency cover: with two sets 42 % of the wave cycles were s_waitcnt vmcnt)
+    float4 ra0[A_CH], ra1[A_CH], ra2[A_CH], ra3[A_CH];
+    float4 rb0[BPRE ? 1 : B_CH], rb1[BPRE ? 1 : B_CH], rb2[BPRE ? 1 : B_CH], rb3[BPRE ? 1 : B_CH];
+    u32x4 r30[BPRE ? B3_CH : 1], r31[BPRE ? B3_CH : 1], r32[BPRE ? B3_CH : 1], r33[BPRE ? B3_CH : 1];
+    float mk0 = 1.f, mk1 = 1.f, mk2 = 1.f, mk3 = 1.f;
+    // Loads are UNCONDITIONAL; tiles past the end re-read the last tile.  Only the last tile of a
+    // segment can reach past round4(K): there the chunk address is clamped into the row (finite
+    // values) and the B side is zero - the fp32 form is multiplied by a 0 / 1 mask when it goes
+    // to LDS, the pre-split image is zero-padded.
+#define MARL_SP_LOAD(S_, q_)                                                               \
     {                                                                                      \
-        const bool live_ = (tile_) < T;                                                    \
-        if (live_ && (tile_) == t0 && t1 > 0) {                                            \
-            set_seg_a(1);                                                                  \
-            if (!BPRE) set_seg_b(1);                                                       \
+        const int qd_ = (q_) < T ? (q_) : T - 1;                                           \
+        const bool s1_ = qd_ >= t0;                                                        \
+        const int tq_ = qd_ - (s1_ ? t0 : 0);                                              \
+        const int kq_ = tq_ * SK;                                                          \
+        const int K4_ = s1_ ? K41 : K40;                                                   \
+        const bool in_ = kq_ + koff < K4_;                                                 \
+        const uint32_t d_ = (uint32_t)((in_ ? koff : K4_ - 4 - kq_) * 4);                  \
+        mk##S_ = in_ ? 1.f : 0.f;                                                          \
+        if (BPRE) {                                                                        \
+            const char* bp_ = (s1_ ? b1p : b0p) + (size_t)tq_ * 192 + (s1_ ? bof1[0] : bof0[0]); \
+            _Pragma("unroll") for (int i = 0; i < B3_CH; ++i)                              \
+                r3##S_[BPRE ? i : 0] = *reinterpret_cast<const u32x4*>(bp_ + (i / BH) * 64 + (i % BH) * 16); \
         }                                                                                  \
-        const int tc_ = live_ ? (tile_) : T - 1;                                           \
-        const int k0_ = (tc_ >= t0 ? tc_ - t0 : tc_) * SK;                                 \
-        masked_ = k0_ + SK > K4cur;                                                        \
-        const int k_ = k0_ + koff;                                                         \
-        const uint32_t d_ = (!masked_ || k_ < K4cur) ? 0u : (uint32_t)((K4cur - 4 - k_) * 4); \
-        mk_ = (!masked_ || k_ < K4cur) ? 1.f : 0.f;                                        \
-        abase -= live_ ? 0 : SK * 4;                                                       \
-        if (!BPRE) bbase -= live_ ? 0 : SK * 4;                                            \
+        const char* ap_ = (s1_ ? a1p : a0p) + (size_t)kq_ * 4;                             \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                   \
-            ra_[i] = *reinterpret_cast<const float4*>(abase + (aof[i] + d_));              \
+            ra##S_[i] = *reinterpret_cast<const float4*>(ap_ + ((s1_ ? aof1[i] : aof0[i]) + d_)); \
         if (!BPRE) {                                                                       \
+            const char* bp_ = (s1_ ? b1p : b0p) + (size_t)kq_ * 4;                         \
             _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                               \
-                rb_[BPRE ? 0 : i] = *reinterpret_cast<const float4*>(bbase + (bof[i] + d_)); \
-            bbase += SK * 4;                                                               \
+                rb##S_[BPRE ? 0 : i] = *reinterpret_cast<const float4*>(                   \
+                    bp_ + ((s1_ ? bof1[BPRE ? 0 : i] : bof0[BPRE ? 0 : i]) + d_));         \
         }                                                                                  \
-        abase += SK * 4;                                                                   \
     }
-#ifdef MARL_KERNEL_TS
-#define MARL_SP_DBGWAIT() if (!BPRE) { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); MARL_TS(); }
-#define MARL_SP_DBGTS() MARL_TS();
-#else
-#define MARL_SP_DBGWAIT()
-#define MARL_SP_DBGTS()
-#endif
-#define MARL_SP_STORE(ra_, rb_, mk_, masked_)                                              \
+#define MARL_SP_STORE(S_, buf_)                                                            \
     {                                                                                      \
-        MARL_SP_DBGWAIT()                                                                  \
+        char* As_ = smem_c + (buf_) * GSZ;                                                 \
+        char* Bs_ = As_ + 3 * APL;                                                         \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                 \
             const int c_ = tid + 256 * i;                                                  \
-            split_store4(As + (c_ / KC) * SROW + (c_ % KC) * 8, APL, ra_[i].x, ra_[i].y,   \
-                         ra_[i].z, ra_[i].w);                                              \
+            split_store4(As_ + (c_ / KC) * SROW + (c_ % KC) * 8, APL, ra##S_[i].x, ra##S_[i].y, \
+                         ra##S_[i].z, ra##S_[i].w);                                        \
         }                                                                                  \
-        MARL_SP_DBGTS()                                                                    \
         if (BPRE) {                                                                        \
-            _Pragma("unroll") for (int i = 0; i < B3_CH; ++i) {                            \
-                const int c_ = tid + 256 * i;                                              \
-                const int rem_ = c_ % 12;                                                  \
-                *reinterpret_cast<u32x4*>(Bs + (rem_ / 4) * BPL + (c_ / 12) * SROW + (rem_ % 4) * 16) = \
-                    rb3[BPRE ? i : 0];                                                     \
-            }                                                                              \
+            char* d3_ = Bs_ + (tid / BR) * SROW + (tid % BR) * (BH * 16);                  \
+            _Pragma("unroll") for (int i = 0; i < B3_CH; ++i)                              \
+                *reinterpret_cast<u32x4*>(d3_ + (i / BH) * BPL + (i % BH) * 16) = r3##S_[BPRE ? i : 0]; \
         } else {                                                                           \
             _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                             \
                 const int c_ = tid + 256 * i;                                              \
-                float4 v_ = rb_[BPRE ? 0 : i];                                             \
-                if (masked_) {                                                             \
-                    v_.x *= mk_;                                                           \
-                    v_.y *= mk_;                                                           \
-                    v_.z *= mk_;                                                           \
-                    v_.w *= mk_;                                                           \
-                }                                                                          \
-                split_store4(Bs + (c_ / KC) * SROW + (c_ % KC) * 8, BPL, v_.x, v_.y, v_.z, v_.w); \
+                const float4 v_ = rb##S_[BPRE ? 0 : i];                                    \
+                split_store4(Bs_ + (c_ / KC) * SROW + (c_ % KC) * 8, BPL, v_.x * mk##S_, v_.y * mk##S_, \
+                             v_.z * mk##S_, v_.w * mk##S_);                                \
             }                                                                              \
         }                                                                                  \
     }
+#define MARL_SP_COMPUTE(buf_)                                                              \
+    split_compute<TM, TN, APL, BPL>(smem_c + (buf_) * GSZ + (wm * (BM / WM) + (lane & 31)) * SROW + (lane >> 5) * 16, \
+                                    smem_c + (buf_) * GSZ + 3 * APL + (wn * (BN / WN) + (lane & 31)) * SROW + (lane >> 5) * 16, acc);
+    // body of tile u = t + j (set j, stage j & 1): request tile u + 4 into the set tile u just
+    // left, split tile u + 1 into the other stage, multiply tile u; one barrier
+#define MARL_SP_BODY(j_, jn_)                                                              \
+    MARL_SP_LOAD(j_, t + j_ + 4)                                                           \
+    MARL_SP_STORE(jn_, (j_ + 1) & 1)                                                       \
+    MARL_SP_COMPUTE(j_ & 1)                                                                \
+    split_pipeline<TM * TN * 12, BPRE ? 3 : 5, (TM + TN) * 6, A_CH + (BPRE ? B3_CH : B_CH)>(); \
+    lds_barrier();
 
-    const char* al = As + (wm * (BM / WM) + (lane & 31)) * SROW + (lane >> 5) * 16;
-    const char* bl = Bs + (wn * (BN / WN) + (lane & 31)) * SROW + (lane >> 5) * 16;
-
-    MARL_TS_DECL(batch.ts);
-    MARL_TS();
-    set_seg_a(0);
-    set_seg_b(0);
-    MARL_SP_LOADB3(0)
-    MARL_SP_LOAD(raX, rbX, mkX, maskedX, 0)
-    MARL_SP_LOAD(raY, rbY, mkY, maskedY, 1)
-    int tile = 0;
-    MARL_TS();
-    for (; tile + 1 < T; tile += 2) {
-        if (tile > 0) lds_barrier();
-        MARL_TS();
-        MARL_SP_STORE(raX, rbX, mkX, maskedX)
-        MARL_TS();
-        lds_barrier();
-        MARL_TS();
-        MARL_SP_LOADB3(tile + 1)
-        MARL_SP_LOAD(raX, rbX, mkX, maskedX, tile + 2)
-        MARL_TS();
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
-        MARL_TS();
-        lds_barrier();
-        MARL_TS();
-        MARL_SP_STORE(raY, rbY, mkY, maskedY)
-        MARL_TS();
-        lds_barrier();
-        MARL_SP_LOADB3(tile + 2)
-        MARL_SP_LOAD(raY, rbY, mkY, maskedY, tile + 3)
-        MARL_TS();
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
-        MARL_TS();
+    MARL_SP_LOAD(0, 0)
+    MARL_SP_LOAD(1, 1)
+    MARL_SP_LOAD(2, 2)
+    MARL_SP_LOAD(3, 3)
+    MARL_SP_STORE(0, 0)
+    lds_barrier();
+    for (int t = 0;; t += 4) {
+        MARL_SP_BODY(0, 1)
+        if (t + 1 >= T) break;
+        MARL_SP_BODY(1, 2)
+        if (t + 2 >= T) break;
+        MARL_SP_BODY(2, 3)
+        if (t + 3 >= T) break;
+        MARL_SP_BODY(3, 0)
+        if (t + 4 >= T) break;
     }
-    if (tile < T) {
-        if (tile > 0) lds_barrier();
-        MARL_SP_STORE(raX, rbX, mkX, maskedX)
-        lds_barrier();
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
-    }
-#undef MARL_SP_LOADB3
 #undef MARL_SP_LOAD
 #undef MARL_SP_STORE
+#undef MARL_SP_COMPUTE
+#undef MARL_SP_BODY
 
     // ---- epilogue: acc[i][j][r] is C[row(r), col], col = lane & 31,
     //      row(r) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -339,8 +344,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
     } else {
         const int unit = n0 + col_l;
         if (unit < N) {
-            // (previous cell state and biases are fetched here: holding them across the K loop
-            // costs 20 registers this kernel does not have at two workgroups per CU)
             const float bi = P.bias[unit], bf = P.bias[N + unit], bg = P.bias[2 * N + unit], bo = P.bias[3 * N + unit];
             float cprev[16];
 #pragma unroll
@@ -379,15 +382,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
 // A thread stages one 4 x 4 block (4 rows x 4 columns) of each operand per tile and transposes
 // it in registers: LDS row = matrix column, 4 consecutive rows r = 8 bytes of a plane.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
+template <bool CSUM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gemm_tn_split_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
     float* __restrict__ out, int ldo, int64_t out_split_stride, int NI, int NJ, int64_t rows,
     int64_t rows_per_split, float* __restrict__ csum, int gx, int gy, int gz) {
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-    constexpr int APL = BM * SROW, BPL = BN * SROW;
+    constexpr int APL = plane_bytes(BM), BPL = plane_bytes(BN);
+    constexpr int GSZ = 3 * (APL + BPL);
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    char* const As = smem_c;
-    char* const Bs = smem_c + 3 * APL;
 
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (gx > 0) xcd_tile(gx, gy, gz, bx, by, bz);
@@ -400,7 +404,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int T = r_end > r_begin ? (int)((r_end - r_begin + SK - 1) / SK) : 0;
+    // T full 32-row tiles go through the pipelined loop, a last partial tile (only the last
+    // slab can have one) through the masked tail below
+    const int64_t nrows = r_end > r_begin ? r_end - r_begin : 0;
+    const int T = (int)(nrows / SK);
+    const int tail = (int)(nrows - (int64_t)T * SK);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -414,94 +422,105 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
     // width; columns past NI / NJ are never stored)
     const int rb = tid & 7, cb = tid >> 3;
     const int ic = i0 + 4 * cb, jc = j0 + 4 * cb;
-    const uint32_t acol = (uint32_t)(ic < NI4 ? ic : NI4 - 4) * 4u;
-    const uint32_t bcol = (uint32_t)(jc < NJ4 ? jc : NJ4 - 4) * 4u;
-    const char* abase = reinterpret_cast<const char*>(A + (size_t)r_begin * lda);
-    const char* bbase = reinterpret_cast<const char*>(B + (size_t)r_begin * ldb);
-    const bool do_csum = csum != nullptr && by == 0;
+    uint32_t aof[4], bof[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aof[q] = ((uint32_t)(4 * rb + q) * (uint32_t)lda + (uint32_t)(ic < NI4 ? ic : NI4 - 4)) * 4u;
+        bof[q] = ((uint32_t)(4 * rb + q) * (uint32_t)ldb + (uint32_t)(jc < NJ4 ? jc : NJ4 - 4)) * 4u;
+    }
+    const char* const abase = reinterpret_cast<const char*>(A + (size_t)r_begin * lda);
+    const char* const bbase = reinterpret_cast<const char*>(B + (size_t)r_begin * ldb);
+    const bool do_csum = CSUM && by == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 raX[4], rbX[4], raY[4], rbY[4];
-    float mX[4] = {1.f, 1.f, 1.f, 1.f}, mY[4] = {1.f, 1.f, 1.f, 1.f};
-    bool maskedX = false, maskedY = false;
-    // unconditional loads; tiles past the end re-read the last tile; rows past r_end are clamped
-    // to the last valid row and the A side zeroed when the tile goes to LDS
-#define MARL_TS_LOAD(ra_, rb_, m_, masked_, tile_)                                         \
+    // four sets of staging registers (see gemm_nt_split_kernel); unconditional loads, tiles past
+    // the end re-read the last full tile (staged into a stage that is never multiplied)
+    float4 ra0[4], rb0[4], ra1[4], rb1[4], ra2[4], rb2[4], ra3[4], rb3[4];
+#define MARL_TS_LOAD(S_, q_)                                                               \
     {                                                                                      \
-        const bool live_ = (tile_) < T;                                                    \
-        abase -= live_ ? (size_t)0 : (size_t)SK * lda * 4;                                 \
-        bbase -= live_ ? (size_t)0 : (size_t)SK * ldb * 4;                                 \
-        const int64_t base_ = r_begin + (int64_t)(live_ ? (tile_) : T - 1) * SK;           \
-        masked_ = base_ + SK > r_end;                                                      \
+        const int qd_ = (q_) < T ? (q_) : (T > 0 ? T - 1 : 0);                             \
+        const char* ap_ = abase + (size_t)qd_ * SK * lda * 4;                              \
+        const char* bp_ = bbase + (size_t)qd_ * SK * ldb * 4;                              \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
-            int rr_ = 4 * rb + q;                                                          \
-            m_[q] = 1.f;                                                                   \
-            if (masked_ && base_ + rr_ >= r_end) {                                         \
-                rr_ = (int)(r_end - 1 - base_);                                            \
-                m_[q] = 0.f;                                                               \
-            }                                                                              \
-            ra_[q] = *reinterpret_cast<const float4*>(abase + ((uint32_t)rr_ * (uint32_t)lda * 4u + acol)); \
-            rb_[q] = *reinterpret_cast<const float4*>(bbase + ((uint32_t)rr_ * (uint32_t)ldb * 4u + bcol)); \
+            ra##S_[q] = *reinterpret_cast<const float4*>(ap_ + aof[q]);                    \
+            rb##S_[q] = *reinterpret_cast<const float4*>(bp_ + bof[q]);                    \
         }                                                                                  \
-        abase += (size_t)SK * lda * 4;                                                     \
-        bbase += (size_t)SK * ldb * 4;                                                     \
     }
-#define MARL_TS_STORE(ra_, rb_, m_, masked_)                                               \
+#define MARL_TS_STORE(S_, buf_, live_)                                                     \
     {                                                                                      \
-        if (masked_) {                                                                     \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                \
-                ra_[q].x *= m_[q];                                                         \
-                ra_[q].y *= m_[q];                                                         \
-                ra_[q].z *= m_[q];                                                         \
-                ra_[q].w *= m_[q];                                                         \
-            }                                                                              \
+        if (CSUM) { /* (tiles past the end are staged too - no branch in the body - with weight 0) */ \
+            const float w_ = (live_) ? 1.f : 0.f;                                          \
+            cs.x += w_ * ((ra##S_[0].x + ra##S_[1].x) + (ra##S_[2].x + ra##S_[3].x));      \
+            cs.y += w_ * ((ra##S_[0].y + ra##S_[1].y) + (ra##S_[2].y + ra##S_[3].y));      \
+            cs.z += w_ * ((ra##S_[0].z + ra##S_[1].z) + (ra##S_[2].z + ra##S_[3].z));      \
+            cs.w += w_ * ((ra##S_[0].w + ra##S_[1].w) + (ra##S_[2].w + ra##S_[3].w));      \
         }                                                                                  \
-        if (do_csum) {                                                                     \
-            cs.x += (ra_[0].x + ra_[1].x) + (ra_[2].x + ra_[3].x);                         \
-            cs.y += (ra_[0].y + ra_[1].y) + (ra_[2].y + ra_[3].y);                         \
-            cs.z += (ra_[0].z + ra_[1].z) + (ra_[2].z + ra_[3].z);                         \
-            cs.w += (ra_[0].w + ra_[1].w) + (ra_[2].w + ra_[3].w);                         \
-        }                                                                                  \
-        char* da_ = As + (4 * cb) * SROW + rb * 8;                                         \
-        char* db_ = Bs + (4 * cb) * SROW + rb * 8;                                         \
-        split_store4(da_, APL, ra_[0].x, ra_[1].x, ra_[2].x, ra_[3].x);                    \
-        split_store4(da_ + SROW, APL, ra_[0].y, ra_[1].y, ra_[2].y, ra_[3].y);             \
-        split_store4(da_ + 2 * SROW, APL, ra_[0].z, ra_[1].z, ra_[2].z, ra_[3].z);         \
-        split_store4(da_ + 3 * SROW, APL, ra_[0].w, ra_[1].w, ra_[2].w, ra_[3].w);         \
-        split_store4(db_, BPL, rb_[0].x, rb_[1].x, rb_[2].x, rb_[3].x);                    \
-        split_store4(db_ + SROW, BPL, rb_[0].y, rb_[1].y, rb_[2].y, rb_[3].y);             \
-        split_store4(db_ + 2 * SROW, BPL, rb_[0].z, rb_[1].z, rb_[2].z, rb_[3].z);         \
-        split_store4(db_ + 3 * SROW, BPL, rb_[0].w, rb_[1].w, rb_[2].w, rb_[3].w);         \
+        char* da_ = smem_c + (buf_) * GSZ + (4 * cb) * SROW + rb * 8;                      \
+        char* db_ = da_ + 3 * APL;                                                         \
+        split_store4(da_, APL, ra##S_[0].x, ra##S_[1].x, ra##S_[2].x, ra##S_[3].x);        \
+        split_store4(da_ + SROW, APL, ra##S_[0].y, ra##S_[1].y, ra##S_[2].y, ra##S_[3].y); \
+        split_store4(da_ + 2 * SROW, APL, ra##S_[0].z, ra##S_[1].z, ra##S_[2].z, ra##S_[3].z); \
+        split_store4(da_ + 3 * SROW, APL, ra##S_[0].w, ra##S_[1].w, ra##S_[2].w, ra##S_[3].w); \
+        split_store4(db_, BPL, rb##S_[0].x, rb##S_[1].x, rb##S_[2].x, rb##S_[3].x);        \
+        split_store4(db_ + SROW, BPL, rb##S_[0].y, rb##S_[1].y, rb##S_[2].y, rb##S_[3].y); \
+        split_store4(db_ + 2 * SROW, BPL, rb##S_[0].z, rb##S_[1].z, rb##S_[2].z, rb##S_[3].z); \
+        split_store4(db_ + 3 * SROW, BPL, rb##S_[0].w, rb##S_[1].w, rb##S_[2].w, rb##S_[3].w); \
     }
-
-    const char* al = As + (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
-    const char* bl = Bs + (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
+#define MARL_TS_COMPUTE(buf_)                                                              \
+    split_compute<TM, TN, APL, BPL>(smem_c + (buf_) * GSZ + (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 16, \
+                                    smem_c + (buf_) * GSZ + 3 * APL + (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 16, acc);
+    // body of tile u = t + j: request tile u + 4, split tile u + 1 (if it exists: the column sums
+    // must see every tile exactly once), multiply tile u; one barrier
+#define MARL_TS_BODY(j_, jn_)                                                              \
+    MARL_TS_LOAD(j_, t + j_ + 4)                                                           \
+    MARL_TS_STORE(jn_, (j_ + 1) & 1, t + j_ + 1 < T)                                       \
+    MARL_TS_COMPUTE(j_ & 1)                                                                \
+    split_pipeline<48, 5, 24, 8>();                                                        \
+    lds_barrier();
 
     if (T > 0) {
-        MARL_TS_LOAD(raX, rbX, mX, maskedX, 0)
-        MARL_TS_LOAD(raY, rbY, mY, maskedY, 1)
+        MARL_TS_LOAD(0, 0)
+        MARL_TS_LOAD(1, 1)
+        MARL_TS_LOAD(2, 2)
+        MARL_TS_LOAD(3, 3)
+        MARL_TS_STORE(0, 0, true)
+        lds_barrier();
+        for (int t = 0;; t += 4) {
+            MARL_TS_BODY(0, 1)
+            if (t + 1 >= T) break;
+            MARL_TS_BODY(1, 2)
+            if (t + 2 >= T) break;
+            MARL_TS_BODY(2, 3)
+            if (t + 3 >= T) break;
+            MARL_TS_BODY(3, 0)
+            if (t + 4 >= T) break;
+        }
     }
-    int tile = 0;
-    for (; tile + 1 < T; tile += 2) {
-        if (tile > 0) lds_barrier();
-        MARL_TS_STORE(raX, rbX, mX, maskedX)
+    if (tail > 0) {  // the slab's last rows: clamped row addresses, A rows past the end zeroed
+        const char* ap_ = abase + (size_t)T * SK * lda * 4;
+        const char* bp_ = bbase + (size_t)T * SK * ldb * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * rb + q;
+            const bool in = rr < tail;
+            const uint32_t back = in ? 0u : (uint32_t)(rr - (tail - 1));
+            const float m = in ? 1.f : 0.f;
+            ra0[q] = *reinterpret_cast<const float4*>(ap_ + (aof[q] - back * (uint32_t)lda * 4u));
+            rb0[q] = *reinterpret_cast<const float4*>(bp_ + (bof[q] - back * (uint32_t)ldb * 4u));
+            ra0[q].x *= m;
+            ra0[q].y *= m;
+            ra0[q].z *= m;
+            ra0[q].w *= m;
+        }
+        MARL_TS_STORE(0, 0, true)
         lds_barrier();
-        MARL_TS_LOAD(raX, rbX, mX, maskedX, tile + 2)
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
+        MARL_TS_COMPUTE(0)
         lds_barrier();
-        MARL_TS_STORE(raY, rbY, mY, maskedY)
-        lds_barrier();
-        MARL_TS_LOAD(raY, rbY, mY, maskedY, tile + 3)
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
-    }
-    if (tile < T) {
-        if (tile > 0) lds_barrier();
-        MARL_TS_STORE(raX, rbX, mX, maskedX)
-        lds_barrier();
-        split_compute<TM, TN, APL, BPL>(al, bl, acc);
     }
 #undef MARL_TS_LOAD
 #undef MARL_TS_STORE
+#undef MARL_TS_COMPUTE
+#undef MARL_TS_BODY
 
     if (do_csum) {  // the 8 threads rb = 0..7 of a column block staged the same 4 columns
         __syncthreads();
@@ -509,21 +528,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
         sh4[rb * 32 + cb] = cs;
         __syncthreads();
         if (tid < 32) {
-            float4 t = sh4[tid];
+            float4 t4 = sh4[tid];
 #pragma unroll
             for (int q = 1; q < 8; ++q) {
                 const float4 u = sh4[q * 32 + tid];
-                t.x += u.x;
-                t.y += u.y;
-                t.z += u.z;
-                t.w += u.w;
+                t4.x += u.x;
+                t4.y += u.y;
+                t4.z += u.z;
+                t4.w += u.w;
             }
             float* co = csum + (size_t)bz * NI;
             const int c0 = i0 + tid * 4;
-            if (c0 < NI) co[c0] = t.x;
-            if (c0 + 1 < NI) co[c0 + 1] = t.y;
-            if (c0 + 2 < NI) co[c0 + 2] = t.z;
-            if (c0 + 3 < NI) co[c0 + 3] = t.w;
+            if (c0 < NI) co[c0] = t4.x;
+            if (c0 + 1 < NI) co[c0 + 1] = t4.y;
+            if (c0 + 2 < NI) co[c0 + 2] = t4.z;
+            if (c0 + 3 < NI) co[c0 + 3] = t4.w;
         }
     }
 
@@ -636,20 +655,19 @@ static int launch_nt_split_variant(dim3 grid, const GemmBatch& batch_in, hipStre
             // 32-bit byte offsets into the image
             if (pre && (int64_t)(LSTM ? 4 : 1) * batch.p[i].n * g.kt3 * 192 >= (1ll << 32)) pre = false;
         }
-    constexpr size_t lds = (size_t)3 * (128 + BN) * SROW;
-#ifdef MARL_KERNEL_TS
-    static long long* d_ts = nullptr;
-    static int calls = 0;
-    const int rec = ts_begin(&d_ts, calls++);
-    batch.ts = rec ? d_ts : nullptr;
-#endif
+    constexpr int lds = 2 * 3 * plane_bytes(128) + 2 * 3 * plane_bytes(BN);  // two stages
+    static bool raised = false;  // > 64 KiB of dynamic LDS: opt in once per instantiation
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<BN, LSTM, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<BN, LSTM, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        raised = true;
+    }
     if (pre)
         hipLaunchKernelGGL((gemm_nt_split_kernel<BN, LSTM, true>), grid, dim3(256), lds, st, batch);
     else
         hipLaunchKernelGGL((gemm_nt_split_kernel<BN, LSTM, false>), grid, dim3(256), lds, st, batch);
-#ifdef MARL_KERNEL_TS
-    if (rec) ts_report(pre ? "nt_split_pre" : "nt_split", d_ts, 4);
-#endif
     return MARL_OK;
 }
 
@@ -671,8 +689,21 @@ int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStre
 int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
                          int64_t stride, int ni, int nj, int64_t rows, int64_t rows_per_split,
                          float* csum, dim3 grid, int gx, int gy, int gz, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), (size_t)3 * 256 * SROW, st, a, lda, b, ldb,
-                       out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
+    constexpr int lds = 2 * 3 * 2 * plane_bytes(128);
+    static bool raised = false;
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_split_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_split_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        raised = true;
+    }
+    if (csum)
+        hipLaunchKernelGGL(gemm_tn_split_kernel<true>, grid, dim3(256), lds, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
+    else
+        hipLaunchKernelGGL(gemm_tn_split_kernel<false>, grid, dim3(256), lds, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
     return MARL_OK;
 }
 
