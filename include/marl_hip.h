@@ -231,6 +231,15 @@ int marl_normalize_positions(const int64_t* pos, float* out, int rows, int h, in
 /* C[M,N] (+)= A[M,K] * B[N,K]^T + bias ; lda/ldb multiples of 4, 16-byte aligned. */
 int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* bias,
                  float* c, int ldc, int m, int n, int k, int accumulate, void* stream);
+/* Same product with B treated as a WEIGHT matrix, the way the episode calls it: its bf16x3 image
+ * (what marl_pack_weights builds inside the weights workspace) is built in image_scratch
+ * (>= marl_gemm_weight_image_bytes(n, k), 256-byte aligned, must stay valid until the product ran)
+ * and the bf16x6 kernel copies its tiles instead of splitting them.  With the knob mfma_split = 0
+ * this is marl_gemm_nt. */
+int marl_gemm_nt_weights(const float* a, int lda, const float* b, int ldb, const float* bias,
+                         float* c, int ldc, int m, int n, int k, int accumulate,
+                         void* image_scratch, void* stream);
+size_t marl_gemm_weight_image_bytes(int n, int k);
 /* C[NI,NJ] = sum_r A[r,i] * B[r,j] over `rows` rows; scratch >= marl_gemm_tn_scratch(). */
 int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc,
                  int ni, int nj, int64_t rows, float* scratch, size_t scratch_bytes, void* stream);

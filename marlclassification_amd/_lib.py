@@ -66,7 +66,7 @@ EXPORTS = (
     "marl_abi_version marl_last_error marl_param_numel marl_workspace_sizes marl_pack_weights "
     "marl_patch_gather marl_transition marl_episode_forward marl_episode_backward "
     "marl_a2c_loss_fwd_bwd marl_adam_step marl_step_forward marl_gemm_nt marl_gemm_tn "
-    "marl_gemm_tn_scratch marl_ln_silu_fwd marl_debug_buffer "
+    "marl_gemm_tn_scratch marl_gemm_nt_weights marl_gemm_weight_image_bytes marl_ln_silu_fwd marl_debug_buffer "
     "marl_profile_begin marl_profile_end marl_normalize_positions "
     "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_draw_episode "
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
@@ -107,6 +107,9 @@ def _declare(lib: C.CDLL) -> None:
                                       [_vp])
     lib.marl_normalize_positions.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     lib.marl_gemm_nt.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.marl_gemm_nt_weights.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]
+    lib.marl_gemm_weight_image_bytes.restype = _sz
+    lib.marl_gemm_weight_image_bytes.argtypes = [_i, _i]
     lib.marl_gemm_tn.argtypes = [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i64, _vp, _sz, _vp]
     lib.marl_gemm_tn_scratch.restype = _sz
     lib.marl_gemm_tn_scratch.argtypes = [_i, _i, _i64]

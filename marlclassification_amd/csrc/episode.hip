@@ -1912,6 +1912,29 @@ int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* 
     return launch_gemm_nt(bt, static_cast<hipStream_t>(stream));
 }
 
+size_t marl_gemm_weight_image_bytes(int n, int k) { return split_image_floats(n, k) * sizeof(float); }
+
+int marl_gemm_nt_weights(const float* a, int lda, const float* b, int ldb, const float* bias, float* c,
+                         int ldc, int m, int n, int k, int accumulate, void* image_scratch, void* stream) {
+    if (!b || !image_scratch || n < 1 || k < 1 || ldb < k) {
+        set_error("gemm_nt_weights: bad argument");
+        return MARL_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SplitBatch sb{};
+    sb.d[0] = SplitDesc{b, image_scratch, n, k, ldb, (k + 31) / 32};
+    sb.count = 1;
+    MARL_TRY(launch_split_weights(sb, st));
+    split_registry_reset();
+    split_registry_add(b, n, ldb, k, image_scratch);
+    GemmBatch bt{};
+    bt.p[0] = gemm_prob(a, lda, b, ldb, k, c, ldc, m, n, bias, accumulate);
+    bt.count = 1;
+    const int rc = launch_gemm_nt(bt, st);
+    split_registry_reset();
+    return rc;
+}
+
 size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows) { return gemm_tn_scratch_bytes(ni, nj, rows); }
 
 int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni, int nj,

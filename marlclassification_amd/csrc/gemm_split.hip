@@ -19,6 +19,8 @@
 //                         [plane][row][32 k] bf16, rows padded to 80 B = conflict-free b128)
 #include <stdlib.h>
 
+#include <utility>
+
 #include "common.h"
 
 namespace marl {
@@ -33,7 +35,9 @@ namespace {
 
 constexpr int SK = 32;     // K depth of a staged tile (two 16-deep MFMA steps)
 constexpr int SROW = 80;   // LDS bytes per tile row: 32 bf16 + 16 B pad
-constexpr int plane_bytes(int rows) { return rows * SROW; }
+// (+64: the planes of an image start 16 banks apart - the three 16-byte stores of a pre-split
+// row that fall into one 8-lane group then never share a bank)
+constexpr int plane_bytes(int rows) { return rows * SROW + 64; }
 
 __device__ __forceinline__ float sigmoid_acc(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) {
@@ -46,6 +50,58 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// Operand tiles are fetched with raw buffer loads written as inline assembly: descriptor + scalar
+// tile offset in SGPRs, ONE persistent 32-bit VGPR offset per chunk, nothing else - and the
+// request stays where it is written.  hipcc would (a) rebuild 64-bit addresses for every plain
+// load, park them in the destination registers of loads still in flight and drain vmcnt at the
+// top of every tile body, and (b) sink the requests of tile u + 4 three bodies down to their
+// first use (even buffer-load builtins marked volatile): measured 37 % of the kernel time.
+//
+// The requested tiles wait in the accumulation registers a[128:255], addressed BY NUMBER from
+// these asm statements only ("raw" storage: no C++ variable lives there).  Giving the compiler
+// asm outputs for data that has not arrived does not work: it copies them (a -> v -> a, to
+// satisfy its own register assignment) before the wait.  The kernels' own register demand
+// stays below a128 - tests/test_host_logic.py::test_split_kernels_leave_the_staging_registers_alone
+// scans the ISA for any compiler-generated access to a[128:255].
+//   araw_load  : buffer_load_dwordx4 a[LO:LO+3]      (vmcnt is counted by hand: buf_wait<N>)
+//   araw_read4 : four v_accvgpr_read into VGPR values (the split arithmetic needs VGPRs)
+//   araw_lds16 : ds_write_b128 straight from a[LO:LO+3] (pre-split weight chunks: no VGPR at all)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kARawBase = 128;
+__device__ __forceinline__ void araw_reserve() { asm volatile("" ::: "a255"); }  // kernel uses all 256 AGPRs
+__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)0xffffffffu);  // num_records: no reliance on the range check
+    r.w = __builtin_amdgcn_readfirstlane(0x00020000);
+    return r;
+}
+template <int LO>
+__device__ __forceinline__ void araw_load(const i32x4& rsrc, uint32_t voff, uint32_t soff) {
+    static_assert(LO >= kARawBase && LO + 3 <= 255 && (LO & 3) == 0, "staging register range");
+    asm volatile("buffer_load_dwordx4 a[%3:%4], %0, %1, %2 offen"
+                 :
+                 : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)soff)), "n"(LO), "n"(LO + 3)
+                 : "memory");
+}
+template <int LO>
+__device__ __forceinline__ void araw_read4(float& x0, float& x1, float& x2, float& x3) {
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\t"
+                 "v_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3)
+                 : "n"(LO), "n"(LO + 1), "n"(LO + 2), "n"(LO + 3));
+}
+template <int LO>
+__device__ __forceinline__ void araw_lds16(uint32_t lds_byte) {
+    asm volatile("ds_write_b128 %0, a[%1:%2]" : : "v"(lds_byte), "n"(LO), "n"(LO + 3) : "memory");
+}
+// all but the N youngest requests have landed
+template <int N>
+__device__ __forceinline__ void buf_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+__device__ __forceinline__ void buf_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // two fp32 values -> one dword (x low half, y high half) per bf16 term
 __device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
@@ -68,82 +124,316 @@ __device__ __forceinline__ void split_store4(char* dst, int plane, float a, floa
     *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(a2, b2);
 }
 
-// Matrix phase of one staged tile.  al / bl: this lane's fragment address in plane 0 of the A / B
-// image (row = tile row of the wave + lane % 32, k = (lane / 32) * 8); planes APL / BPL bytes apart.
-// All 12 + 12 fragment reads of the tile are issued up front (the wave has the registers), the
-// MFMAs walk the accumulators round robin, smallest terms first.
+// ---------------------------------------------------------------------------
+// Hand-placed software pipeline.  One wave per SIMD (256 threads, one workgroup per CU, two LDS
+// stages, up to 512 registers) runs, for every 32-deep K tile u, a BODY of NM matrix
+// instructions on LDS stage u % 2 while it splits tile u + 1 (already in registers) into the
+// other stage and requests tile u + 4.  A wave issues in order, so the staging work only
+// overlaps with the matrix pipe if it sits BETWEEN the MFMAs in program order: slot m of a body
+// = MFMA m + a slice of the staging arithmetic (a few single-issue instructions, which run in
+// the 32-cycle shadow of the MFMA: MI355X_MICROARCH.md) + at most one LDS access, pinned by
+// sched_barrier.  Left to itself hipcc emits the whole split as ONE block in front of 48
+// back-to-back MFMAs - no overlap, 2.1 us per tile instead of 0.8 (measured, as were two
+// independent workgroups per CU and a ping-pong pair of wave groups: both ~1.5 us per tile).
+//
+// Staging arithmetic of a set of NP value pairs, in lock step (all pairs take step s before any
+// takes step s + 1: seven dependent steps, 11 VALU per pair):
+//   A: p0 = cvt(x)   B: t = unpack(p0)   C: x -= t   D: p1 = cvt(x)   E: t = unpack(p1)
+//   F: x -= t        G: p2 = cvt(x)
+// chunk c = pairs 2c, 2c + 1 = 8 bytes per plane; its plane-0 / 1 / 2 store follows the last
+// op of step A / D / G it needs.
+// ---------------------------------------------------------------------------
+#ifdef MARL_KERNEL_TS
+// cycle stamps kept in scalar registers (s_memtime; the lgkmcnt wait also completes the wave's
+// LDS traffic - diagnosis only)
+__device__ __forceinline__ uint64_t ts_stamp() {
+    uint64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define MARL_STAMP(i_) if (ts_on) ts_v[i_] = ts_stamp();
+#else
+#define MARL_STAMP(i_)
+#endif
+
 template <int TM, int TN>
-struct SplitFrags {
-    bf16x8 a[3][TM], b[3][TN];
+struct Frags {
+    bf16x8 a[2][3][TM], b[2][3][TN];
 };
-template <int TM, int TN, int APL, int BPL>
-__device__ __forceinline__ void split_read(const char* al, const char* bl, int kk, SplitFrags<TM, TN>& f) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            f.a[p][i] = *reinterpret_cast<const bf16x8*>(al + p * APL + i * 32 * SROW + kk * 32);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            f.b[p][j] = *reinterpret_cast<const bf16x8*>(bl + p * BPL + j * 32 * SROW + kk * 32);
+
+template <int NP>
+struct SplitRegs {
+    uint32_t p0[NP], p1[NP], p2[NP];
+};
+
+// MFMA m of a body: the first half of a body multiplies the SECOND 16-deep step of the previous
+// tile (its fragments were read during that tile's body), the second half the first step of
+// the current tile (read at the top of this body): every fragment read has half a body to
+// land, nothing waits for LDS behind the barrier.  Products smallest terms first,
+// accumulators round robin.
+template <int TM, int TN, int m>
+__device__ __forceinline__ void mfma_slot(const Frags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+    constexpr int per = 6 * TM * TN, kk = m < per ? 1 : 0, rem = m % per;
+    constexpr int pi = rem / (TM * TN), q = rem % (TM * TN), i = q / TN, j = q % TN;
+    constexpr int pa = pi == 0 ? 1 : (pi == 2 ? 2 : (pi == 4 ? 1 : 0));
+    constexpr int pb = pi == 0 ? 1 : (pi == 1 ? 2 : (pi == 3 ? 1 : 0));
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kk][pa][i], f.b[kk][pb][j], acc[i][j], 0, 0, 0);
+}
+// fragment read r (0 .. 3 (TM + TN) - 1) of the 16-deep step kk
+template <int TM, int TN, int APL, int BPL, int kk, int r>
+__device__ __forceinline__ void frag_read(const char* al, const char* bl, Frags<TM, TN>& f) {
+    if constexpr (r < 3 * TM)
+        f.a[kk][r / TM][r % TM] = *reinterpret_cast<const bf16x8*>(al + (r / TM) * APL + (r % TM) * 32 * SROW + kk * 32);
+    else
+        f.b[kk][(r - 3 * TM) / TN][(r - 3 * TM) % TN] = *reinterpret_cast<const bf16x8*>(
+            bl + ((r - 3 * TM) / TN) * BPL + ((r - 3 * TM) % TN) * 32 * SROW + kk * 32);
+}
+template <int TM, int TN, int APL, int BPL, int kk, int... R>
+__device__ __forceinline__ void frag_read_all(const char* al, const char* bl, Frags<TM, TN>& f,
+                                              std::integer_sequence<int, R...>) {
+    (frag_read<TM, TN, APL, BPL, kk, R>(al, bl, f), ...);
+}
+
+// Element layout of a staged set.  NT: x[4 c + e] = element e of chunk c (consecutive k).
+// TN: x[16 o + 4 q + c] = operand o, tile row 4 rb + q, column 4 cb + c; chunk (o, c) = the four
+// rows of a column (the 4 x 4 register transpose).
+template <bool TRANS>
+struct SetMap {
+    static constexpr int e0(int pr) { return TRANS ? (pr / 8) * 16 + (2 * (pr % 2)) * 4 + (pr % 8) / 2 : 2 * pr; }
+    static constexpr int e1(int pr) { return TRANS ? e0(pr) + 4 : 2 * pr + 1; }
+};
+
+// op n (0 .. 11 NP - 1) of the lock-step split of x; the chunk stores ride behind the ops that
+// complete them.  dst(c) = wbase + WOFF(c); planes PL bytes apart.
+template <int NP, bool TRANS, int PL, int n>
+__device__ __forceinline__ void split_op(float (&x)[2 * NP], SplitRegs<NP>& r, char* wbase) {
+    // steps: A (NP cvt) | BC (2 NP x {unpack, subtract}) | D (NP cvt) | EF (2 NP x 2) | G (NP cvt);
+    // op n counts single instructions: 11 per pair
+    constexpr int sA = NP, sC = sA + 4 * NP, sD = sC + NP, sF = sD + 4 * NP;
+    using M = SetMap<TRANS>;
+    // byte offset of chunk c from wbase.  NT: chunk c = tile row + 32 c.  TN: operand o = c / 4
+    // (its image 3 planes further), column c % 4 = next LDS row
+    auto woff = [](int c) constexpr { return TRANS ? (c / 4) * 3 * PL + (c % 4) * SROW : c * 32 * SROW; };
+    if constexpr (n < sA) {
+        r.p0[n] = pack_bf16(x[M::e0(n)], x[M::e1(n)]);
+        if constexpr (n & 1) *reinterpret_cast<uint2*>(wbase + woff(n / 2)) = make_uint2(r.p0[n - 1], r.p0[n]);
+    } else if constexpr (n < sC) {
+        // element m = (n - sA) / 2: the op pair {unpack its bf16 term, subtract}; done on the odd op
+        if constexpr ((n - sA) & 1) {
+            constexpr int m = (n - sA) / 2;
+            x[(m & 1) ? M::e1(m / 2) : M::e0(m / 2)] -=
+                (m & 1) ? __uint_as_float(r.p0[m / 2] & 0xffff0000u) : __uint_as_float(r.p0[m / 2] << 16);
+        }
+    } else if constexpr (n < sD) {
+        constexpr int m = n - sC;
+        r.p1[m] = pack_bf16(x[M::e0(m)], x[M::e1(m)]);
+        if constexpr (m & 1) *reinterpret_cast<uint2*>(wbase + woff(m / 2) + PL) = make_uint2(r.p1[m - 1], r.p1[m]);
+    } else if constexpr (n < sF) {
+        if constexpr ((n - sD) & 1) {
+            constexpr int m = (n - sD) / 2;
+            x[(m & 1) ? M::e1(m / 2) : M::e0(m / 2)] -=
+                (m & 1) ? __uint_as_float(r.p1[m / 2] & 0xffff0000u) : __uint_as_float(r.p1[m / 2] << 16);
+        }
+    } else if constexpr (n < 11 * NP) {
+        constexpr int m = n - sF;
+        r.p2[m] = pack_bf16(x[M::e0(m)], x[M::e1(m)]);
+        if constexpr (m & 1) *reinterpret_cast<uint2*>(wbase + woff(m / 2) + 2 * PL) = make_uint2(r.p2[m - 1], r.p2[m]);
     }
 }
-template <int TM, int TN>
-__device__ __forceinline__ void split_mfma(const SplitFrags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+template <int NP, bool TRANS, int PL, int... N>
+__device__ __forceinline__ void split_ops(float (&x)[2 * NP], SplitRegs<NP>& r, char* wbase,
+                                          std::integer_sequence<int, N...>) {
+    (split_op<NP, TRANS, PL, N>(x, r, wbase), ...);
+}
+template <int FIRST, int... N>
+constexpr auto seq_from(std::integer_sequence<int, N...>) { return std::integer_sequence<int, (FIRST + N)...>{}; }
+template <int FIRST, int COUNT>
+constexpr auto seq_range() { return seq_from<FIRST>(std::make_integer_sequence<int, (COUNT > 0 ? COUNT : 0)>{}); }
+
+// One pipelined body: NM MFMAs, every one followed by its slice of everything else the wave has
+// to issue for this tile step (the "items" below), pinned by sched_barrier.  Nothing but the
+// wait for the set about to be staged precedes the first MFMA.
+//   slot m < NCH          : chunk m of the staged set -> VGPR values (Ops::take<m>)
+//   slot m >= NCH         : Q ops of the lock-step split of those values (+ the LDS stores
+//                           that ride behind them)
+//   first half, in order  : this tile's first-step fragment reads, the pre-split B chunk
+//                           copies, this body's memory requests (Ops::request<k>)
+//   second half           : this tile's second-step fragment reads (used in the NEXT body; the
+//                           first half still multiplies the previous tile's)
+// Ops (kernel specific, all static-index templates): take<c>(x), request<k>(), copy_b3<i>().
+template <int TM, int TN, int APL, int BPL, int NP, bool TRANS, int B3N, int NREQ, class Ops>
+struct Body {
+    static constexpr int NM = 12 * TM * TN;
+    static constexpr int NR = 3 * (TM + TN);  // fragment reads per 16-deep step
+    static constexpr int NCH = NP / 2;        // chunks of the staged set
+    static constexpr int Q = (11 * NP + (NM - NCH) - 1) / (NM - NCH);
+    static constexpr int NF = NR + B3N + NREQ;                  // first-half items
+    static constexpr int PF = (NF + NM / 2 - 1) / (NM / 2);     // ... per slot
+    static constexpr int PS = (NR + NM / 2 - 1) / (NM / 2);     // second-half items per slot
+    static_assert(NCH < NM && PF >= 1 && PS >= 1, "slot plan");
+
+    template <int i>
+    static __device__ __forceinline__ void first_item(const char* al, const char* bl, Frags<TM, TN>& f, Ops& o) {
+        if constexpr (i < NR) {
+#ifndef MARL_EXP_NOREAD
+            frag_read<TM, TN, APL, BPL, 0, i>(al, bl, f);
+#endif
+        } else if constexpr (i < NR + B3N) {
+            o.template copy_b3<i - NR>();
+        } else if constexpr (i < NF) {
+            o.template request<i - NR - B3N>();
+        }
+    }
+    template <int... I>
+    static __device__ __forceinline__ void first_items(const char* al, const char* bl, Frags<TM, TN>& f, Ops& o,
+                                                       std::integer_sequence<int, I...>) {
+        (first_item<I>(al, bl, f, o), ...);
+    }
+    template <int... I>
+    static __device__ __forceinline__ void second_items(const char* al, const char* bl, Frags<TM, TN>& f,
+                                                        std::integer_sequence<int, I...>) {
+#ifndef MARL_EXP_NOREAD
+        ((I < NR ? frag_read<TM, TN, APL, BPL, 1, (I < NR ? I : 0)>(al, bl, f) : (void)0), ...);
+#endif
+    }
+    template <int m>
+    static __device__ __forceinline__ void slot(const char* al, const char* bl, Frags<TM, TN>& f,
+                                                f32x16 (&acc)[TM][TN], float (&x)[2 * NP], SplitRegs<NP>& r,
+                                                char* wbase, Ops& o) {
+        mfma_slot<TM, TN, m>(f, acc);
+#ifndef MARL_EXP_NOSTAGE
+        if constexpr (m < NCH)
+            o.template take<m>(x);
+        else
+            split_ops<NP, TRANS, APL>(x, r, wbase, seq_range<(m - NCH) * Q, Q>());
+#endif
+        if constexpr (m < NM / 2)
+            first_items(al, bl, f, o, seq_range<m * PF, PF>());
+        else
+            second_items(al, bl, f, seq_range<(m - NM / 2) * PS, PS>());
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int... M>
+    static __device__ __forceinline__ void slots(const char* al, const char* bl, Frags<TM, TN>& f,
+                                                 f32x16 (&acc)[TM][TN], float (&x)[2 * NP], SplitRegs<NP>& r,
+                                                 char* wbase, Ops& o, std::integer_sequence<int, M...>) {
+        (slot<M>(al, bl, f, acc, x, r, wbase, o), ...);
+    }
+    // the second step of the last tile (after the loop)
+    template <int... M>
+    static __device__ __forceinline__ void flush_(const Frags<TM, TN>& f, f32x16 (&acc)[TM][TN],
+                                                  std::integer_sequence<int, M...>) {
+        (mfma_slot<TM, TN, M>(f, acc), ...);
+    }
+    static __device__ __forceinline__ void flush(const Frags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+        flush_(f, acc, std::make_integer_sequence<int, NM / 2>{});
+    }
+    // before the first body: no previous tile - its "second step" multiplies zeros
+    static __device__ __forceinline__ void init(Frags<TM, TN>& f) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f.a[1][p][i][e] = 0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f.b[1][p][j][e] = 0;
+        }
+    }
+    static __device__ __forceinline__ void run(const char* al, const char* bl, Frags<TM, TN>& f,
+                                               f32x16 (&acc)[TM][TN], float (&x)[2 * NP], SplitRegs<NP>& r,
+                                               char* wbase, Ops& o) {
+        slots(al, bl, f, acc, x, r, wbase, o, std::make_integer_sequence<int, NM>{});
+    }
+};
+
+// ---- per-kernel item providers --------------------------------------------------------------
+// NT: A set S at a[ALO + 16 S], pre-split B set P at a[BLO + 24 P]; this body stages A set SN and
+// B set PN, and requests B tile -> set PR, then A tile -> set SR
+template <int B3N, int ALO, int BLO, int SN, int PN, int SR, int PR>
+struct NtOps {
+    const i32x4& rsa;
+    const i32x4& rsb;
+    const uint32_t (&cao)[4];
+    const uint32_t (&vb3)[B3N];
+    const uint32_t (&db3)[B3N];
+    uint32_t so_a, so_b, b3dst;
+    template <int c>
+    __device__ __forceinline__ void take(float (&x)[16]) {
+        araw_read4<ALO + 16 * SN + 4 * c>(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+    }
+    template <int i>
+    __device__ __forceinline__ void copy_b3() { araw_lds16<BLO + 24 * PN + 4 * i>(b3dst + db3[i]); }
+    template <int k>
+    __device__ __forceinline__ void request() {
+        if constexpr (k < B3N)
+            araw_load<BLO + 24 * PR + 4 * k>(rsb, vb3[k], so_b);
+        else
+            araw_load<ALO + 16 * SR + 4 * (k - B3N)>(rsa, cao[k - B3N], so_a);
+    }
+};
+// TN: set S at a[128 + 32 S]: A rows q = 0..3, then B rows
+template <int SN, int SR>
+struct TnOps {
+    const i32x4& rsa;
+    const i32x4& rsb;
+    const uint32_t (&aof)[4];
+    const uint32_t (&bof)[4];
+    uint32_t so_a, so_b;
+    template <int c>
+    __device__ __forceinline__ void take(float (&x)[32]) {
+        // chunk c of the split = column c % 4 of operand c / 4; its four values are rows q = 0..3:
+        // elements 16 o + 4 q + col.  Take the staged vector c (row c % 4 of operand c / 4) instead:
+        // by chunk 8 every element is there, and the first split op only runs in slot 8
+        araw_read4<kARawBase + 32 * SN + 4 * c>(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+    }
+    template <int i>
+    __device__ __forceinline__ void copy_b3() {}
+    template <int k>
+    __device__ __forceinline__ void request() {
+        if constexpr (k < 4)
+            araw_load<kARawBase + 32 * SR + 4 * k>(rsa, aof[k], so_a);
+        else
+            araw_load<kARawBase + 32 * SR + 16 + 4 * (k - 4)>(rsb, bof[k - 4], so_b);
+    }
+};
+
+// plain (not pipelined) matrix phase of one staged tile: tails
+template <int TM, int TN, int APL, int BPL>
+__device__ __forceinline__ void split_compute(const char* al, const char* bl, f32x16 (&acc)[TM][TN]) {
+    Frags<TM, TN> f;
+    frag_read_all<TM, TN, APL, BPL, 0>(al, bl, f, std::make_integer_sequence<int, 3 * (TM + TN)>{});
+    frag_read_all<TM, TN, APL, BPL, 1>(al, bl, f, std::make_integer_sequence<int, 3 * (TM + TN)>{});
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
 #define MARL_SPLIT_P(pa_, pb_)                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[pa_][i], f.b[pb_][j], acc[i][j], 0, 0, 0);
-    MARL_SPLIT_P(1, 1) MARL_SPLIT_P(0, 2) MARL_SPLIT_P(2, 0)
-    MARL_SPLIT_P(0, 1) MARL_SPLIT_P(1, 0) MARL_SPLIT_P(0, 0)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kk][pa_][i], f.b[kk][pb_][j], acc[i][j], 0, 0, 0);
+        MARL_SPLIT_P(1, 1) MARL_SPLIT_P(0, 2) MARL_SPLIT_P(2, 0)
+        MARL_SPLIT_P(0, 1) MARL_SPLIT_P(1, 0) MARL_SPLIT_P(0, 0)
 #undef MARL_SPLIT_P
-}
-template <int TM, int TN, int APL, int BPL>
-__device__ __forceinline__ void split_compute(const char* al, const char* bl, f32x16 (&acc)[TM][TN]) {
-    SplitFrags<TM, TN> f0, f1;
-    split_read<TM, TN, APL, BPL>(al, bl, 0, f0);
-    split_read<TM, TN, APL, BPL>(al, bl, 1, f1);
-    split_mfma<TM, TN>(f0, acc);
-    split_mfma<TM, TN>(f1, acc);
-}
-
-// Issue order of one pipelined tile body (a single scheduling region): the fragment reads and
-// the memory requests first, then every MFMA followed by NV single-issue instructions of the
-// staging arithmetic (they run in the 32-cycle shadow of the matrix instruction) and, every
-// other MFMA, one LDS store.  hipcc by itself emits the staging arithmetic as ONE block in
-// front of 48 back-to-back MFMAs (no overlap at all: 2.1 us per tile instead of 0.8).
-template <int NMFMA, int NV, int NREAD, int NVMEM>
-__device__ __forceinline__ void split_pipeline() {
-    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);   // DS reads
-    __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);   // VMEM reads
-#pragma unroll
-    for (int m = 0; m < NMFMA; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU
-        if (m & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
     }
 }
 
 }  // namespace
 
-// ---------------------------------------------------------------------------
-// Both kernels are software-pipelined inside ONE wave per SIMD (256 threads, one workgroup per
-// CU, two LDS stages of 60 KB, up to 512 registers): while the 48 MFMAs of tile t run from LDS
-// stage t % 2, the same wave splits tile t + 1 (already in registers) into the other stage and
-// issues the loads of tile t + 3 - the VALU / LDS / memory instructions sit in the 32-cycle
-// shadows of the matrix instructions (tools/ubench_split.hip; MI355X_MICROARCH.md: up to 5
-// single-issue instructions per v_mfma_f32_32x32x16_bf16), one barrier per tile.  Two
-// independent workgroups per CU measured 2x slower per phase (they drift into lockstep), a
-// ping-pong pair of wave groups likewise.
-// ---------------------------------------------------------------------------
+#ifdef MARL_EXP_NOBAR
+#define MARL_EXP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MARL_EXP_BARRIER() lds_barrier()
+#endif
 
 // ---------------------------------------------------------------------------
-// NT: C[M,N] (+)= sum_s A_s[M,K_s] * B_s[N,K_s]^T + bias, optional LSTM-cell epilogue; 128 x BN tiles.
-// BPRE: the B operands are weights whose bf16x3 image already exists in the weights workspace
-// (split_weights_kernel: [row][k / 32][plane][32] bf16, zero-padded to whole K tiles) - their tiles
-// are copied, not split.
+// NT: C[M,N] (+)= sum_s A_s[M,K_s] * B_s[N,K_s]^T + bias, optional LSTM-cell epilogue; 128 x BN
+// tiles.  The B operands are weights whose bf16x3 image exists in the weights workspace
+// (split_weights_kernel: [row][k / 32][plane][32] bf16, zero-padded to whole K tiles): their
+// tiles are copied, only A is split.  (Products with other B operands take the exact-fp32
+// kernel of gemm.hip.)
 // ---------------------------------------------------------------------------
-template <int BN, bool LSTM, bool BPRE>
+template <int BN, bool LSTM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gemm_nt_split_kernel(const GemmBatch batch) {
     constexpr int BM = 128;
@@ -151,16 +441,13 @@ void gemm_nt_split_kernel(const GemmBatch batch) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KC = SK / 4;                 // float4 chunks per tile row
     constexpr int A_CH = BM * KC / 256;        // 4
-    constexpr int B_CH = BN * KC / 256;        // 4 or 2
     constexpr int B3_CH = BN * 12 / 256;       // 16-byte chunks of a pre-split B tile per thread
     constexpr int APL = plane_bytes(BM), BPL = plane_bytes(BN);
     constexpr int GSZ = 3 * (APL + BPL);       // LDS bytes of one stage
-    // A pre-split B tile row is 3 planes x 64 bytes: the 256 / BN threads of a row take the
-    // 16-byte columns [h * BH, +BH) of every plane - one global offset and one LDS address per
-    // thread plus immediates cover all of a thread's chunks.
-    constexpr int BR = 256 / BN;   // threads per B row: 2 or 4
-    constexpr int BH = 4 / BR;     // 16-byte columns per thread and plane: 2 or 1
-    static_assert(3 * BH == B3_CH, "chunk count");
+    constexpr int NP = 2 * A_CH;   // value pairs a thread splits per tile
+    // staging registers (raw AGPRs): A set S, chunk i at a[128 + 16 S + 4 i]; B set P, chunk i at
+    // a[192 + 24 P + 4 i]
+    constexpr int ALO = kARawBase, BLO = kARawBase + 64;
     static_assert(!LSTM || BN == 128, "LSTM tile = 4 gates x 32 units");
 
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -181,11 +468,10 @@ void gemm_nt_split_kernel(const GemmBatch batch) {
     const int ks0 = P.seg[0].k, ks1 = P.nseg > 1 ? P.seg[1].k : 0;
     const int t0 = (ks0 + SK - 1) / SK;
     const int T = t0 + (ks1 + SK - 1) / SK;
-    const int K40 = (ks0 + 3) & ~3, K41 = (ks1 + 3) & ~3;
     const char* const a0p = reinterpret_cast<const char*>(P.seg[0].a);
     const char* const a1p = reinterpret_cast<const char*>(P.seg[1].a);
-    const char* const b0p = reinterpret_cast<const char*>(BPRE ? P.seg[0].b3 : (const void*)P.seg[0].b);
-    const char* const b1p = reinterpret_cast<const char*>(BPRE ? P.seg[1].b3 : (const void*)P.seg[1].b);
+    const char* const b0p = reinterpret_cast<const char*>(P.seg[0].b3);
+    const char* const b1p = reinterpret_cast<const char*>(P.seg[1].b3);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -195,11 +481,10 @@ void gemm_nt_split_kernel(const GemmBatch batch) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging: thread t moves A chunks c = t + 256 i (tile row c / KC, floats [(c % KC) * 4, +4)),
-    // fp32 B likewise.  Rows beyond M / N are clamped (never stored).  Byte offsets of both
-    // segments are kept in registers (this kernel has 512 of them).
+    // staging: thread t moves A chunks c = t + 256 i (tile row c / KC, floats [(c % KC) * 4, +4)).
+    // Rows beyond M / N are clamped (never stored).  Byte offsets of both segments stay in registers.
     const int koff = (tid % KC) * 4;
-    uint32_t aof0[A_CH], aof1[A_CH], bof0[BPRE ? 1 : B_CH], bof1[BPRE ? 1 : B_CH];
+    uint32_t aof0[A_CH], aof1[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         int r = m0 + (tid + 256 * i) / KC;
@@ -207,10 +492,16 @@ void gemm_nt_split_kernel(const GemmBatch batch) {
         aof0[i] = (uint32_t)r * (uint32_t)P.seg[0].lda * 4u;
         aof1[i] = (uint32_t)r * (uint32_t)P.seg[1].lda * 4u;
     }
+    // A pre-split B tile = BN rows x 192 bytes, and the image is tile-major: rows n0 .. n0 + BN - 1
+    // of a K tile are contiguous (LSTM: four blocks of 32 rows).  Thread t copies the 16-byte
+    // chunks c = t + 256 i (row c / 12, plane (c % 12) / 4, column (c % 12) % 4): a wave's 64
+    // chunks are 1 KB of consecutive bytes - whole cache lines.  Same offsets in both segments.
+    uint32_t vb3[B3_CH];   // byte offset of chunk i inside a K tile of the image
+    uint32_t db3[B3_CH];   // its place in the LDS image (relative to the B image of a stage)
 #pragma unroll
-    for (int i = 0; i < (BPRE ? 1 : B_CH); ++i) {
-        const int row = BPRE ? tid / BR : (tid + 256 * i) / KC;
-        int gn;
+    for (int i = 0; i < B3_CH; ++i) {
+        const int c = tid + 256 * i, row = c / 12, rem = c % 12;
+        int gn;  // row of the image, relative to the row the segment's b3 points at
         if (LSTM) {
             int unit = n0 + (row & 31);
             unit = unit < N ? unit : N - 1;
@@ -219,103 +510,98 @@ void gemm_nt_split_kernel(const GemmBatch batch) {
             gn = n0 + row;
             gn = gn < N ? gn : N - 1;
         }
-        if (BPRE) {  // row gn of the image: kt tiles of 192 bytes; this thread's byte column
-            bof0[i] = (uint32_t)gn * (uint32_t)P.seg[0].kt3 * 192u + (uint32_t)(tid % BR) * (BH * 16);
-            bof1[i] = (uint32_t)gn * (uint32_t)P.seg[1].kt3 * 192u + (uint32_t)(tid % BR) * (BH * 16);
-        } else {
-            bof0[i] = (uint32_t)gn * (uint32_t)P.seg[0].ldb * 4u;
-            bof1[i] = (uint32_t)gn * (uint32_t)P.seg[1].ldb * 4u;
-        }
+        vb3[i] = (uint32_t)gn * 192u + (uint32_t)rem * 16u;
+        db3[i] = (uint32_t)((rem / 4) * BPL + row * SROW + (rem % 4) * 16);
     }
 
-    // four sets of staging registers: tile u + 4 is requested while tile u is multiplied (three
-    // tile times of latency cover: with two sets 42 % of the wave cycles were s_waitcnt vmcnt)
-    float4 ra0[A_CH], ra1[A_CH], ra2[A_CH], ra3[A_CH];
-    float4 rb0[BPRE ? 1 : B_CH], rb1[BPRE ? 1 : B_CH], rb2[BPRE ? 1 : B_CH], rb3[BPRE ? 1 : B_CH];
-    u32x4 r30[BPRE ? B3_CH : 1], r31[BPRE ? B3_CH : 1], r32[BPRE ? B3_CH : 1], r33[BPRE ? B3_CH : 1];
-    float mk0 = 1.f, mk1 = 1.f, mk2 = 1.f, mk3 = 1.f;
-    // Loads are UNCONDITIONAL; tiles past the end re-read the last tile.  Only the last tile of a
-    // segment can reach past round4(K): there the chunk address is clamped into the row (finite
-    // values) and the B side is zero - the fp32 form is multiplied by a 0 / 1 mask when it goes
-    // to LDS, the pre-split image is zero-padded.
-#define MARL_SP_LOAD(S_, q_)                                                               \
-    {                                                                                      \
-        const int qd_ = (q_) < T ? (q_) : T - 1;                                           \
-        const bool s1_ = qd_ >= t0;                                                        \
-        const int tq_ = qd_ - (s1_ ? t0 : 0);                                              \
-        const int kq_ = tq_ * SK;                                                          \
-        const int K4_ = s1_ ? K41 : K40;                                                   \
-        const bool in_ = kq_ + koff < K4_;                                                 \
-        const uint32_t d_ = (uint32_t)((in_ ? koff : K4_ - 4 - kq_) * 4);                  \
-        mk##S_ = in_ ? 1.f : 0.f;                                                          \
-        if (BPRE) {                                                                        \
-            const char* bp_ = (s1_ ? b1p : b0p) + (size_t)tq_ * 192 + (s1_ ? bof1[0] : bof0[0]); \
-            _Pragma("unroll") for (int i = 0; i < B3_CH; ++i)                              \
-                r3##S_[BPRE ? i : 0] = *reinterpret_cast<const u32x4*>(bp_ + (i / BH) * 64 + (i % BH) * 16); \
-        }                                                                                  \
-        const char* ap_ = (s1_ ? a1p : a0p) + (size_t)kq_ * 4;                             \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                   \
-            ra##S_[i] = *reinterpret_cast<const float4*>(ap_ + ((s1_ ? aof1[i] : aof0[i]) + d_)); \
-        if (!BPRE) {                                                                       \
-            const char* bp_ = (s1_ ? b1p : b0p) + (size_t)kq_ * 4;                         \
-            _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                               \
-                rb##S_[BPRE ? 0 : i] = *reinterpret_cast<const float4*>(                   \
-                    bp_ + ((s1_ ? bof1[BPRE ? 0 : i] : bof0[BPRE ? 0 : i]) + d_));         \
-        }                                                                                  \
-    }
-#define MARL_SP_STORE(S_, buf_)                                                            \
-    {                                                                                      \
-        char* As_ = smem_c + (buf_) * GSZ;                                                 \
-        char* Bs_ = As_ + 3 * APL;                                                         \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                 \
-            const int c_ = tid + 256 * i;                                                  \
-            split_store4(As_ + (c_ / KC) * SROW + (c_ % KC) * 8, APL, ra##S_[i].x, ra##S_[i].y, \
-                         ra##S_[i].z, ra##S_[i].w);                                        \
-        }                                                                                  \
-        if (BPRE) {                                                                        \
-            char* d3_ = Bs_ + (tid / BR) * SROW + (tid % BR) * (BH * 16);                  \
-            _Pragma("unroll") for (int i = 0; i < B3_CH; ++i)                              \
-                *reinterpret_cast<u32x4*>(d3_ + (i / BH) * BPL + (i % BH) * 16) = r3##S_[BPRE ? i : 0]; \
-        } else {                                                                           \
-            _Pragma("unroll") for (int i = 0; i < B_CH; ++i) {                             \
-                const int c_ = tid + 256 * i;                                              \
-                const float4 v_ = rb##S_[BPRE ? 0 : i];                                    \
-                split_store4(Bs_ + (c_ / KC) * SROW + (c_ % KC) * 8, BPL, v_.x * mk##S_, v_.y * mk##S_, \
-                             v_.z * mk##S_, v_.w * mk##S_);                                \
-            }                                                                              \
-        }                                                                                  \
-    }
-#define MARL_SP_COMPUTE(buf_)                                                              \
-    split_compute<TM, TN, APL, BPL>(smem_c + (buf_) * GSZ + (wm * (BM / WM) + (lane & 31)) * SROW + (lane >> 5) * 16, \
-                                    smem_c + (buf_) * GSZ + 3 * APL + (wn * (BN / WN) + (lane & 31)) * SROW + (lane >> 5) * 16, acc);
-    // body of tile u = t + j (set j, stage j & 1): request tile u + 4 into the set tile u just
-    // left, split tile u + 1 into the other stage, multiply tile u; one barrier
-#define MARL_SP_BODY(j_, jn_)                                                              \
-    MARL_SP_LOAD(j_, t + j_ + 4)                                                           \
-    MARL_SP_STORE(jn_, (j_ + 1) & 1)                                                       \
-    MARL_SP_COMPUTE(j_ & 1)                                                                \
-    split_pipeline<TM * TN * 12, BPRE ? 3 : 5, (TM + TN) * 6, A_CH + (BPRE ? B3_CH : B_CH)>(); \
-    lds_barrier();
+    // staging: A (from HBM) four sets - tile u + 4 is requested while tile u is multiplied; the
+    // pre-split B tiles (L2-resident weights) two sets, two tiles ahead.
+    // Requests are UNCONDITIONAL; tiles past the end re-read the last tile.  The last tile of a
+    // segment may reach past K: those A chunks read on into the next row (or up to 112 bytes past
+    // the last row - A operands are slices of the episode workspace, whose every float is
+    // finite) and meet the zero padding of the B image.  Chunk offsets / descriptor / tile
+    // stride in use change ONCE per request stream, when it crosses into the second segment.
+    araw_reserve();
+    uint32_t cao[A_CH], cts = P.seg[0].ts3;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) cao[i] = aof0[i] + (uint32_t)koff * 4u;
+    i32x4 rsa = make_rsrc(a0p), rsb = make_rsrc(b0p);
+    static_assert(A_CH == 4, "four A chunks per thread and tile");
+    // scalar part of the requests of A tile qa and B tile qb (each stream switches segment once)
+#define MARL_SP_SCALARS(qa_, qb_)                                                          \
+    if ((qa_) == t0 && (qa_) < T) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) cao[i] = aof1[i] + (uint32_t)koff * 4u; \
+        rsa = make_rsrc(a1p);                                                              \
+    }                                                                                      \
+    if ((qb_) == t0 && (qb_) < T) {                                                        \
+        cts = P.seg[1].ts3;                                                                \
+        rsb = make_rsrc(b1p);                                                              \
+    }                                                                                      \
+    const int qda_ = (qa_) < T ? (qa_) : T - 1, qdb_ = (qb_) < T ? (qb_) : T - 1;          \
+    const uint32_t so_a_ = (uint32_t)(qda_ - (qda_ >= t0 ? t0 : 0)) * (SK * 4);            \
+    const uint32_t so_b_ = (uint32_t)(qdb_ - (qdb_ >= t0 ? t0 : 0)) * cts;
 
-    MARL_SP_LOAD(0, 0)
-    MARL_SP_LOAD(1, 1)
-    MARL_SP_LOAD(2, 2)
-    MARL_SP_LOAD(3, 3)
-    MARL_SP_STORE(0, 0)
-    lds_barrier();
+    // LDS addresses of this thread: A chunk 0 (chunk i is 32 rows further), its fragments - in
+    // stage 0; stage 1 is GSZ bytes further.  (The dynamic LDS starts at byte 0.)
+    char* const wa = smem_c + (tid / KC) * SROW + (tid % KC) * 8;
+    constexpr uint32_t wb3 = 3 * APL;  // B image of stage 0
+    const char* const al = smem_c + (wm * (BM / WM) + (lane & 31)) * SROW + (lane >> 5) * 16;
+    const char* const bl = smem_c + 3 * APL + (wn * (BN / WN) + (lane & 31)) * SROW + (lane >> 5) * 16;
+    Frags<TM, TN> fr;
+    float xs[2 * NP];
+    SplitRegs<NP> sr;
+    // body of tile u = t + j (A set j, stage j & 1): multiply tile u while tile u + 1 (A set jn,
+    // B set 1 - par) goes to the other stage; request B tile u + 2 into B set par (tile u's:
+    // copied during the previous body) and A tile u + 4 into A set j.  Landed before the body:
+    // everything but the previous body's A request.
+#define MARL_SP_BODY(j_, jn_, par_)                                                        \
+    {                                                                                      \
+        MARL_SP_SCALARS(t + j_ + 4, t + j_ + 2)                                            \
+        using O_ = NtOps<B3_CH, ALO, BLO, jn_, 1 - par_, j_, par_>;                        \
+        using B_ = Body<TM, TN, APL, BPL, NP, false, B3_CH, A_CH + B3_CH, O_>;             \
+        O_ o_{rsa, rsb, cao, vb3, db3, so_a_, so_b_, wb3 + ((j_ + 1) & 1) * GSZ};          \
+        buf_wait<A_CH>();                                                                  \
+        B_::run(al + (j_ & 1) * GSZ, bl + (j_ & 1) * GSZ, fr, acc, xs, sr, wa + ((j_ + 1) & 1) * GSZ, o_); \
+        MARL_EXP_BARRIER();                                                                \
+    }
+    using O0 = NtOps<B3_CH, ALO, BLO, 0, 0, 0, 0>;
+    using B0 = Body<TM, TN, APL, BPL, NP, false, B3_CH, A_CH + B3_CH, O0>;
+    B0::init(fr);
+    {   // prologue: requests of tiles 0..3 (B: 0, 1), tile 0 -> stage 0 (plain)
+        { MARL_SP_SCALARS(0, 0) O0 o{rsa, rsb, cao, vb3, db3, so_a_, so_b_, wb3};
+          o.template request<0>(); o.template request<1 % B3_CH>(); o.template request<2 % B3_CH>();
+          if (B3_CH > 3) { o.template request<3 % B3_CH>(); o.template request<4 % B3_CH>(); o.template request<5 % B3_CH>(); }
+          o.template request<B3_CH>(); o.template request<B3_CH + 1>(); o.template request<B3_CH + 2>(); o.template request<B3_CH + 3>(); }
+        { MARL_SP_SCALARS(1, 1) NtOps<B3_CH, ALO, BLO, 0, 0, 1, 1> o{rsa, rsb, cao, vb3, db3, so_a_, so_b_, wb3};
+          o.template request<0>(); o.template request<1 % B3_CH>(); o.template request<2 % B3_CH>();
+          if (B3_CH > 3) { o.template request<3 % B3_CH>(); o.template request<4 % B3_CH>(); o.template request<5 % B3_CH>(); }
+          o.template request<B3_CH>(); o.template request<B3_CH + 1>(); o.template request<B3_CH + 2>(); o.template request<B3_CH + 3>(); }
+        { MARL_SP_SCALARS(2, 1) NtOps<B3_CH, ALO, BLO, 0, 0, 2, 1> o{rsa, rsb, cao, vb3, db3, so_a_, so_b_, wb3};
+          o.template request<B3_CH>(); o.template request<B3_CH + 1>(); o.template request<B3_CH + 2>(); o.template request<B3_CH + 3>(); }
+        { MARL_SP_SCALARS(3, 1) NtOps<B3_CH, ALO, BLO, 0, 0, 3, 1> o{rsa, rsb, cao, vb3, db3, so_a_, so_b_, wb3};
+          o.template request<B3_CH>(); o.template request<B3_CH + 1>(); o.template request<B3_CH + 2>(); o.template request<B3_CH + 3>(); }
+        buf_wait<3 * A_CH + B3_CH>();  // tile 0 (A and B) has landed
+        O0 o{rsa, rsb, cao, vb3, db3, 0u, 0u, wb3};
+        o.template take<0>(xs); o.template take<1>(xs); o.template take<2>(xs); o.template take<3>(xs);
+        split_ops<NP, false, APL>(xs, sr, wa, std::make_integer_sequence<int, 11 * NP>{});
+        o.template copy_b3<0>(); o.template copy_b3<1 % B3_CH>(); o.template copy_b3<2 % B3_CH>();
+        if (B3_CH > 3) { o.template copy_b3<3 % B3_CH>(); o.template copy_b3<4 % B3_CH>(); o.template copy_b3<5 % B3_CH>(); }
+        lds_barrier();
+    }
+    // (the prologue already requested B tile 1 into set 1: body 0 requests B tile 2 into set 0, ...)
     for (int t = 0;; t += 4) {
-        MARL_SP_BODY(0, 1)
+        MARL_SP_BODY(0, 1, 0)
         if (t + 1 >= T) break;
-        MARL_SP_BODY(1, 2)
+        MARL_SP_BODY(1, 2, 1)
         if (t + 2 >= T) break;
-        MARL_SP_BODY(2, 3)
+        MARL_SP_BODY(2, 3, 0)
         if (t + 3 >= T) break;
-        MARL_SP_BODY(3, 0)
+        MARL_SP_BODY(3, 0, 1)
         if (t + 4 >= T) break;
     }
-#undef MARL_SP_LOAD
-#undef MARL_SP_STORE
-#undef MARL_SP_COMPUTE
+    buf_drain();  // (requests of tiles past the end are still in flight)
+    B0::flush(fr, acc);
+#undef MARL_SP_SCALARS
 #undef MARL_SP_BODY
 
     // ---- epilogue: acc[i][j][r] is C[row(r), col], col = lane & 31,
@@ -433,58 +719,74 @@ void gemm_tn_split_kernel(
     const bool do_csum = CSUM && by == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // four sets of staging registers (see gemm_nt_split_kernel); unconditional loads, tiles past
-    // the end re-read the last full tile (staged into a stage that is never multiplied)
-    float4 ra0[4], rb0[4], ra1[4], rb1[4], ra2[4], rb2[4], ra3[4], rb3[4];
-#define MARL_TS_LOAD(S_, q_)                                                               \
-    {                                                                                      \
-        const int qd_ = (q_) < T ? (q_) : (T > 0 ? T - 1 : 0);                             \
-        const char* ap_ = abase + (size_t)qd_ * SK * lda * 4;                              \
-        const char* bp_ = bbase + (size_t)qd_ * SK * ldb * 4;                              \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
-            ra##S_[q] = *reinterpret_cast<const float4*>(ap_ + aof[q]);                    \
-            rb##S_[q] = *reinterpret_cast<const float4*>(bp_ + bof[q]);                    \
-        }                                                                                  \
+    // four sets of staging registers (see gemm_nt_split_kernel): set S at a[128 + 32 S], A rows
+    // q = 0..3 then B rows; unconditional requests, tiles past the end re-read the last full tile
+    // (staged into a stage that is never multiplied)
+    constexpr int NP = 16;  // value pairs per tile: 4 x 4 block of A + 4 x 4 block of B
+    araw_reserve();
+    float xs[2 * NP];
+    const i32x4 rsa = make_rsrc(abase), rsb = make_rsrc(bbase);
+    const uint32_t tsa = (uint32_t)SK * (uint32_t)lda * 4u, tsb = (uint32_t)SK * (uint32_t)ldb * 4u;  // tile strides
+    char* const wbase = smem_c + (4 * cb) * SROW + rb * 8;  // column 4 cb of the A image, stage 0
+    const char* const al = smem_c + (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
+    const char* const bl = smem_c + 3 * APL + (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
+    Frags<TM, TN> fr;
+    SplitRegs<NP> sr;
+    using O0 = TnOps<0, 0>;
+    using Bd0 = Body<TM, TN, APL, BPL, NP, true, 0, 8, O0>;
+    // column sums of A (the bias gradient) from the raw values of the set that body u - 1 staged
+    // (tile u): read once more from the staging registers, which the next request into that set
+    // has not touched yet - it is issued later in the same body.  Tiles past the end: weight 0.
+#define MARL_TS_CSUM(S_, live_)                                                            \
+    if (CSUM) {                                                                            \
+        float c_[16];                                                                      \
+        araw_read4<kARawBase + 32 * S_>(c_[0], c_[1], c_[2], c_[3]);                       \
+        araw_read4<kARawBase + 32 * S_ + 4>(c_[4], c_[5], c_[6], c_[7]);                   \
+        araw_read4<kARawBase + 32 * S_ + 8>(c_[8], c_[9], c_[10], c_[11]);                 \
+        araw_read4<kARawBase + 32 * S_ + 12>(c_[12], c_[13], c_[14], c_[15]);              \
+        const float w_ = (live_) ? 1.f : 0.f;                                              \
+        cs.x += w_ * ((c_[0] + c_[4]) + (c_[8] + c_[12]));                                 \
+        cs.y += w_ * ((c_[1] + c_[5]) + (c_[9] + c_[13]));                                 \
+        cs.z += w_ * ((c_[2] + c_[6]) + (c_[10] + c_[14]));                                \
+        cs.w += w_ * ((c_[3] + c_[7]) + (c_[11] + c_[15]));                                \
     }
-#define MARL_TS_STORE(S_, buf_, live_)                                                     \
-    {                                                                                      \
-        if (CSUM) { /* (tiles past the end are staged too - no branch in the body - with weight 0) */ \
-            const float w_ = (live_) ? 1.f : 0.f;                                          \
-            cs.x += w_ * ((ra##S_[0].x + ra##S_[1].x) + (ra##S_[2].x + ra##S_[3].x));      \
-            cs.y += w_ * ((ra##S_[0].y + ra##S_[1].y) + (ra##S_[2].y + ra##S_[3].y));      \
-            cs.z += w_ * ((ra##S_[0].z + ra##S_[1].z) + (ra##S_[2].z + ra##S_[3].z));      \
-            cs.w += w_ * ((ra##S_[0].w + ra##S_[1].w) + (ra##S_[2].w + ra##S_[3].w));      \
-        }                                                                                  \
-        char* da_ = smem_c + (buf_) * GSZ + (4 * cb) * SROW + rb * 8;                      \
-        char* db_ = da_ + 3 * APL;                                                         \
-        split_store4(da_, APL, ra##S_[0].x, ra##S_[1].x, ra##S_[2].x, ra##S_[3].x);        \
-        split_store4(da_ + SROW, APL, ra##S_[0].y, ra##S_[1].y, ra##S_[2].y, ra##S_[3].y); \
-        split_store4(da_ + 2 * SROW, APL, ra##S_[0].z, ra##S_[1].z, ra##S_[2].z, ra##S_[3].z); \
-        split_store4(da_ + 3 * SROW, APL, ra##S_[0].w, ra##S_[1].w, ra##S_[2].w, ra##S_[3].w); \
-        split_store4(db_, BPL, rb##S_[0].x, rb##S_[1].x, rb##S_[2].x, rb##S_[3].x);        \
-        split_store4(db_ + SROW, BPL, rb##S_[0].y, rb##S_[1].y, rb##S_[2].y, rb##S_[3].y); \
-        split_store4(db_ + 2 * SROW, BPL, rb##S_[0].z, rb##S_[1].z, rb##S_[2].z, rb##S_[3].z); \
-        split_store4(db_ + 3 * SROW, BPL, rb##S_[0].w, rb##S_[1].w, rb##S_[2].w, rb##S_[3].w); \
-    }
-#define MARL_TS_COMPUTE(buf_)                                                              \
-    split_compute<TM, TN, APL, BPL>(smem_c + (buf_) * GSZ + (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 16, \
-                                    smem_c + (buf_) * GSZ + 3 * APL + (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 16, acc);
-    // body of tile u = t + j: request tile u + 4, split tile u + 1 (if it exists: the column sums
-    // must see every tile exactly once), multiply tile u; one barrier
+    // body of tile u = t + j: multiply tile u while tile u + 1 (set jn) is split into the other
+    // stage; request tile u + 4 into set j.  Landed before the body: all but the two youngest sets.
 #define MARL_TS_BODY(j_, jn_)                                                              \
-    MARL_TS_LOAD(j_, t + j_ + 4)                                                           \
-    MARL_TS_STORE(jn_, (j_ + 1) & 1, t + j_ + 1 < T)                                       \
-    MARL_TS_COMPUTE(j_ & 1)                                                                \
-    split_pipeline<48, 5, 24, 8>();                                                        \
-    lds_barrier();
+    {                                                                                      \
+        const uint32_t qd_ = (uint32_t)(t + j_ + 4 < T ? t + j_ + 4 : T - 1);              \
+        using O_ = TnOps<jn_, j_>;                                                         \
+        using B_ = Body<TM, TN, APL, BPL, NP, true, 0, 8, O_>;                             \
+        O_ o_{rsa, rsb, aof, bof, qd_ * tsa, qd_ * tsb};                                   \
+        buf_wait<16>();                                                                    \
+        MARL_TS_CSUM(jn_, t + j_ + 1 < T)                                                  \
+        B_::run(al + (j_ & 1) * GSZ, bl + (j_ & 1) * GSZ, fr, acc, xs, sr, wbase + ((j_ + 1) & 1) * GSZ, o_); \
+        MARL_EXP_BARRIER();                                                                \
+    }
 
     if (T > 0) {
-        MARL_TS_LOAD(0, 0)
-        MARL_TS_LOAD(1, 1)
-        MARL_TS_LOAD(2, 2)
-        MARL_TS_LOAD(3, 3)
-        MARL_TS_STORE(0, 0, true)
-        lds_barrier();
+        Bd0::init(fr);
+        {   // prologue: requests of tiles 0..3, tile 0 -> stage 0 (plain)
+#define MARL_TS_REQ(S_, q_)                                                                \
+    {                                                                                      \
+        const uint32_t qd_ = (uint32_t)((q_) < T ? (q_) : T - 1);                          \
+        TnOps<0, S_> o{rsa, rsb, aof, bof, qd_ * tsa, qd_ * tsb};                          \
+        o.template request<0>(); o.template request<1>(); o.template request<2>(); o.template request<3>(); \
+        o.template request<4>(); o.template request<5>(); o.template request<6>(); o.template request<7>(); \
+    }
+            MARL_TS_REQ(0, 0)
+            MARL_TS_REQ(1, 1)
+            MARL_TS_REQ(2, 2)
+            MARL_TS_REQ(3, 3)
+#undef MARL_TS_REQ
+            buf_wait<24>();
+            MARL_TS_CSUM(0, true)
+            O0 o{rsa, rsb, aof, bof, 0u, 0u};
+            o.template take<0>(xs); o.template take<1>(xs); o.template take<2>(xs); o.template take<3>(xs);
+            o.template take<4>(xs); o.template take<5>(xs); o.template take<6>(xs); o.template take<7>(xs);
+            split_ops<NP, true, APL>(xs, sr, wbase, std::make_integer_sequence<int, 11 * NP>{});
+            lds_barrier();
+        }
         for (int t = 0;; t += 4) {
             MARL_TS_BODY(0, 1)
             if (t + 1 >= T) break;
@@ -495,6 +797,8 @@ void gemm_tn_split_kernel(
             MARL_TS_BODY(3, 0)
             if (t + 4 >= T) break;
         }
+        buf_drain();  // (requests of tiles past the end are still in flight)
+        Bd0::flush(fr, acc);
     }
     if (tail > 0) {  // the slab's last rows: clamped row addresses, A rows past the end zeroed
         const char* ap_ = abase + (size_t)T * SK * lda * 4;
@@ -505,21 +809,29 @@ void gemm_tn_split_kernel(
             const bool in = rr < tail;
             const uint32_t back = in ? 0u : (uint32_t)(rr - (tail - 1));
             const float m = in ? 1.f : 0.f;
-            ra0[q] = *reinterpret_cast<const float4*>(ap_ + (aof[q] - back * (uint32_t)lda * 4u));
-            rb0[q] = *reinterpret_cast<const float4*>(bp_ + (bof[q] - back * (uint32_t)ldb * 4u));
-            ra0[q].x *= m;
-            ra0[q].y *= m;
-            ra0[q].z *= m;
-            ra0[q].w *= m;
+            const float4 va = *reinterpret_cast<const float4*>(ap_ + (aof[q] - back * (uint32_t)lda * 4u));
+            const float4 vb = *reinterpret_cast<const float4*>(bp_ + (bof[q] - back * (uint32_t)ldb * 4u));
+            xs[4 * q] = va.x * m;
+            xs[4 * q + 1] = va.y * m;
+            xs[4 * q + 2] = va.z * m;
+            xs[4 * q + 3] = va.w * m;
+            xs[16 + 4 * q] = vb.x;
+            xs[16 + 4 * q + 1] = vb.y;
+            xs[16 + 4 * q + 2] = vb.z;
+            xs[16 + 4 * q + 3] = vb.w;
         }
-        MARL_TS_STORE(0, 0, true)
+        if (CSUM) {
+            cs.x += (xs[0] + xs[4]) + (xs[8] + xs[12]);
+            cs.y += (xs[1] + xs[5]) + (xs[9] + xs[13]);
+            cs.z += (xs[2] + xs[6]) + (xs[10] + xs[14]);
+            cs.w += (xs[3] + xs[7]) + (xs[11] + xs[15]);
+        }
+        split_ops<NP, true, APL>(xs, sr, wbase, std::make_integer_sequence<int, 11 * NP>{});
         lds_barrier();
-        MARL_TS_COMPUTE(0)
+        split_compute<TM, TN, APL, BPL>(al, bl, acc);
         lds_barrier();
     }
-#undef MARL_TS_LOAD
-#undef MARL_TS_STORE
-#undef MARL_TS_COMPUTE
+#undef MARL_TS_CSUM
 #undef MARL_TS_BODY
 
     if (do_csum) {  // the 8 threads rb = 0..7 of a column block staged the same 4 columns
@@ -572,9 +884,9 @@ __global__ void split_weights_kernel(const SplitBatch B) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int pr = (int)(idx & 15);
-        const int64_t rt = idx >> 4;  // row * kt + tile
-        const int t = (int)(rt % d.kt);
-        const int64_t r = rt / d.kt;
+        const int64_t rt = idx >> 4;  // tile * rows + row
+        const int t = (int)(rt / d.rows);
+        const int64_t r = rt % d.rows;
         const int k = t * 32 + pr * 2;
         const float x = k < d.k ? d.src[r * d.ld + k] : 0.f;
         const float y = k + 1 < d.k ? d.src[r * d.ld + k + 1] : 0.f;
@@ -614,14 +926,16 @@ struct SplitReg {
 SplitReg g_reg[kMaxSplitDesc];
 int g_nreg = 0;
 // b = base + row0 * ld of a registered matrix with the same row stride and depth -> its image rows
-bool split_lookup(const GemmSeg& g, const void*& b3, int& kt) {
+bool split_lookup(const GemmSeg& g, const void*& b3, uint32_t& ts) {
     for (int i = 0; i < g_nreg; ++i) {
         const SplitReg& r = g_reg[i];
         if (g.b < r.base || g.b >= r.base + r.floats || g.ldb != r.ld || g.k != r.k) continue;
         const size_t off = (size_t)(g.b - r.base);
         if (off % (size_t)r.ld) return false;
-        kt = (r.k + 31) / 32;
-        b3 = r.image + (off / (size_t)r.ld) * (size_t)kt * 192;
+        const size_t rows = r.floats / (size_t)r.ld;
+        if (rows * 192 * (size_t)((r.k + 31) / 32) >= (1ull << 32)) return false;  // 32-bit tile offsets
+        ts = (uint32_t)(rows * 192);
+        b3 = r.image + (off / (size_t)r.ld) * 192;
         return true;
     }
     return false;
@@ -639,41 +953,62 @@ void split_registry_add(const float* base, int rows, int ld, int k, const void* 
 // ---------------------------------------------------------------------------
 int split_mode() { return tune_get("mfma_split", 1); }
 
+// every B operand must be a registered weight matrix (its pre-split image is what the kernel
+// copies); *ok = false -> the caller takes the exact-fp32 kernel instead
+static bool split_prepare(GemmBatch& batch, bool lstm) {
+    if (!tune_get("split_pre", 1)) return false;
+    for (int i = 0; i < batch.count; ++i)
+        for (int sg = 0; sg < batch.p[i].nseg; ++sg) {
+            GemmSeg& g = batch.p[i].seg[sg];
+            if (!split_lookup(g, g.b3, g.ts3)) return false;
+        }
+    return true;
+}
+
 template <int BN, bool LSTM>
-static int launch_nt_split_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t st) {
-    GemmBatch batch = batch_in;
+static int launch_nt_split_variant(dim3 grid, GemmBatch& batch, hipStream_t st) {
     batch.gx = (int)grid.x;
     batch.gy = (int)grid.y;
     batch.xcd_map = batch.count == 1 && !LSTM && tune_get("nt_xcd", 1);
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
-    // every B operand a registered weight matrix: the kernel copies their pre-split tiles
-    bool pre = tune_get("split_pre", 1) != 0;
-    for (int i = 0; i < batch.count && pre; ++i)
-        for (int sg = 0; sg < batch.p[i].nseg && pre; ++sg) {
-            GemmSeg& g = batch.p[i].seg[sg];
-            pre = split_lookup(g, g.b3, g.kt3);
-            // 32-bit byte offsets into the image
-            if (pre && (int64_t)(LSTM ? 4 : 1) * batch.p[i].n * g.kt3 * 192 >= (1ll << 32)) pre = false;
-        }
     constexpr int lds = 2 * 3 * plane_bytes(128) + 2 * 3 * plane_bytes(BN);  // two stages
     static bool raised = false;  // > 64 KiB of dynamic LDS: opt in once per instantiation
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<BN, LSTM, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<BN, LSTM, false>),
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<BN, LSTM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         raised = true;
     }
-    if (pre)
-        hipLaunchKernelGGL((gemm_nt_split_kernel<BN, LSTM, true>), grid, dim3(256), lds, st, batch);
-    else
-        hipLaunchKernelGGL((gemm_nt_split_kernel<BN, LSTM, false>), grid, dim3(256), lds, st, batch);
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts = nullptr;
+    static int calls = 0;
+    const int rec = ts_begin(&d_ts, calls++);
+    batch.ts = rec ? d_ts : nullptr;
+#endif
+    hipLaunchKernelGGL((gemm_nt_split_kernel<BN, LSTM>), grid, dim3(256), lds, st, batch);
+#ifdef MARL_KERNEL_TS
+    if (rec) {
+        long long h[9];
+        (void)hipMemcpy(h, d_ts, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[ts] nt_split body (cycles): top %lld | slots0-11 %lld | 12-23 %lld | 24-35 %lld | 36-47 %lld | barrier %lld | total %lld\n",
+                h[1] - h[0], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[7] - h[5], h[8] - h[7], h[8] - h[0]);
+    }
+#endif
     return MARL_OK;
 }
 
-int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st) {
-    // 128-wide column tiles when they fill the chip (two workgroups per CU), else 128 x 64
-    if (blocks128 >= tune_get("nts_min_blocks128", 384) && max_n >= 96) {
+// returns MARL_OK with *done = 0 when the batch cannot take the bf16x6 kernel
+int launch_gemm_nt_split(const GemmBatch& batch_in, int max_m, int max_n, int64_t blocks128, hipStream_t st,
+                         int* done) {
+    GemmBatch batch = batch_in;
+    *done = 0;
+    if (!split_prepare(batch, false)) return MARL_OK;
+    *done = 1;
+    // one workgroup per CU: 128-wide column tiles unless 128 x 64 tiles fit one round of 256
+    // workgroups better
+    int64_t blocks64 = 0;
+    for (int i = 0; i < batch.count; ++i) blocks64 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 64);
+    const bool wide = blocks128 >= tune_get("nts_min_blocks128", 192) || blocks64 > 256;
+    if (wide && max_n >= 96) {
         dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         return launch_nt_split_variant<128, false>(grid, batch, st);
     }
@@ -681,7 +1016,11 @@ int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t b
     return launch_nt_split_variant<64, false>(grid, batch, st);
 }
 
-int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStream_t st) {
+int launch_gemm_lstm_split(const GemmBatch& batch_in, int max_m, int max_n, hipStream_t st, int* done) {
+    GemmBatch batch = batch_in;
+    *done = 0;
+    if (!split_prepare(batch, true)) return MARL_OK;
+    *done = 1;
     dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
     return launch_nt_split_variant<128, true>(grid, batch, st);
 }

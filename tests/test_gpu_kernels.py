@@ -42,7 +42,8 @@ def _padded(t, ld):
                                    (4096, 512, 368), (3000, 130, 7), (300, 2048, 624),
                                    (32768 + 77, 368, 200)])  # last: many row blocks, ragged M and N
 @pytest.mark.parametrize("acc", [0, 1])
-def test_gemm_nt(device, mfma_split, m, n, k, acc):
+@pytest.mark.parametrize("weights", [0, 1], ids=["plainB", "weightB"])
+def test_gemm_nt(device, mfma_split, m, n, k, acc, weights):
     lib, check = _lib()
     g = th.Generator().manual_seed(m * 7 + n * 3 + k)
     a = th.randn(m, k, generator=g)
@@ -54,8 +55,18 @@ def test_gemm_nt(device, mfma_split, m, n, k, acc):
     cd = th.zeros(m, ldc, device=device)
     cd[:, :n] = c0.to(device)
     bias_d = bias.to(device)
-    check(lib.marl_gemm_nt(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1],
-                           bias_d.data_ptr(), cd.data_ptr(), ldc, m, n, k, acc, None))
+    if weights:  # B as a weight matrix: pre-split image, the path every product of the episode takes
+        img = th.zeros(lib.marl_gemm_weight_image_bytes(n, k) // 4 + 64, device=device)
+        # (A as in the episode: a slice of a larger finite workspace - the kernel may read up to
+        # 112 bytes past the last row's K columns)
+        ws = th.zeros(ad.numel() + 64, device=device)
+        ws[: ad.numel()] = ad.flatten()
+        check(lib.marl_gemm_nt_weights(ws.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1],
+                                       bias_d.data_ptr(), cd.data_ptr(), ldc, m, n, k, acc,
+                                       img.data_ptr(), None))
+    else:
+        check(lib.marl_gemm_nt(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1],
+                               bias_d.data_ptr(), cd.data_ptr(), ldc, m, n, k, acc, None))
     th.cuda.synchronize()
     ref = a.double() @ b.double().t() + bias.double() + (c0.double() if acc else 0)
     err = (cd[:, :n].cpu().double() - ref).abs().max().item()

@@ -3,13 +3,20 @@ sys.path.insert(0, os.getcwd())
 from marlclassification_amd import _lib
 lib, check = _lib.load(), _lib.check
 dev = th.device("cuda:0")
-m, n, k = 128, 64, 64
-for case in ("ones", "a_tile1_only", "b_tile1_only"):
-    a = th.ones(m, k); b = th.ones(n, k)
-    if case == "a_tile1_only": a[:, :32] = 0; a[:, 32:] = th.arange(32).float() + 1
-    if case == "b_tile1_only": b[:, :32] = 0; b[:, 32:] = th.arange(32).float() + 1
-    ad, bd = a.to(dev), b.to(dev); c = th.zeros(m, n, device=dev)
-    check(lib.marl_gemm_nt(ad.data_ptr(), k, bd.data_ptr(), k, None, c.data_ptr(), n, m, n, k, 0, None))
+for (m, n, k) in [(128, 128, 32), (128, 128, 64), (128, 128, 128), (128, 64, 160), (256, 512, 96), (4096, 256, 1024), (95, 45, 24)]:
+    g = th.Generator().manual_seed(1)
+    a = th.randn(m, k, generator=g); b = th.randn(n, k, generator=g)
+    k4 = (k + 3) & ~3
+    ws = th.zeros(m * k4 + 64, device=dev); ad = ws[: m * k4].view(m, k4); ad[:, :k] = a.to(dev)
+    bd = th.zeros(n, k4, device=dev); bd[:, :k] = b.to(dev)
+    c = th.zeros(m, n, device=dev)
+    img = th.zeros(lib.marl_gemm_weight_image_bytes(n, k) // 4 + 64, device=dev)
+    check(lib.marl_gemm_nt_weights(ad.data_ptr(), k4, bd.data_ptr(), k4, None, c.data_ptr(), n, m, n, k, 0, img.data_ptr(), None))
     th.cuda.synchronize()
     ref = a @ b.t()
-    print(case, "ref", ref[0, 0].item(), "got", c[0, :4].cpu().tolist(), c[64:66, 32:34].cpu().tolist())
+    err = (c.cpu() - ref).abs()
+    print(m, n, k, "max err", err.max().item(), flush=True)
+    if err.max() > 1e-3:
+        for t in range((k + 31) // 32):
+            part = a[:, t*32:(t+1)*32] @ b[:, t*32:(t+1)*32].t()
+            print("   tile", t, "corr:", ((ref - c.cpu()) * part).sum().item() / (part * part).sum().item())

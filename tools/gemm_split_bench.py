@@ -44,13 +44,17 @@ for m, n, k in NT:
     g = th.Generator().manual_seed(m + n + k)
     a = th.randn(m, k, generator=g)
     b = th.randn(n, k, generator=g) / k ** 0.5
-    ad, bd = padded(a.to(dev), p4(k)), padded(b.to(dev), p4(k))
+    ws = th.zeros(m * p4(k) + 64, device=dev)
+    ad = ws[: m * p4(k)].view(m, p4(k))
+    ad[:, :k] = a.to(dev)
+    bd = padded(b.to(dev), p4(k))
     ref = (a[:2048].double() @ b.double().t())
     for mode in (0, 1):
         check(lib.marl_tune(b"mfma_split", mode))
         cd = th.zeros(m, p4(n), device=dev)
-        fn = lambda: check(lib.marl_gemm_nt(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1], None,
-                                            cd.data_ptr(), cd.shape[1], m, n, k, 0, None))
+        img = th.zeros(lib.marl_gemm_weight_image_bytes(n, k) // 4 + 64, device=dev)
+        fn = lambda: check(lib.marl_gemm_nt_weights(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1], None,
+                                                    cd.data_ptr(), cd.shape[1], m, n, k, 0, img.data_ptr(), None))
         us = timeit(fn)
         err = (cd[:2048, :n].cpu().double() - ref).abs().max().item()
         rows.append(dict(kind="nt", m=m, n=n, k=k, split=mode, us=round(us, 1),

@@ -10,8 +10,9 @@ x, y, z = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 if kind == "nt":
     m, n, k = x, y, z
     a = th.randn(m, k, device=dev); b = th.randn(n, k, device=dev); c = th.zeros(m, n, device=dev)
+    img = th.zeros(lib.marl_gemm_weight_image_bytes(n, k) // 4 + 64, device=dev)
     for i in range(8):
-        check(lib.marl_gemm_nt(a.data_ptr(), k, b.data_ptr(), k, None, c.data_ptr(), n, m, n, k, 0, None))
+        check(lib.marl_gemm_nt_weights(a.data_ptr(), k, b.data_ptr(), k, None, c.data_ptr(), n, m, n, k, 0, img.data_ptr(), None))
 else:
     r, ni, nj = x, y, z
     a = th.randn(r, ni, device=dev); b = th.randn(r, nj, device=dev); c = th.zeros(ni, nj, device=dev)
