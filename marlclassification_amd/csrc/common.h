@@ -67,11 +67,10 @@ struct GemmSeg {
     const float* a;
     const float* b;
     int lda, ldb, k;
-    // filled by the bf16x6 launcher when b is a registered weight matrix: row b's position in
-    // its pre-split image [k / 32][row][plane][32] bf16, and the bytes from one 32-deep K tile
-    // of the image to the next (= 192 x rows of the whole matrix)
+    // filled by the bf16x6 launcher when b is a registered weight matrix: its pre-split image
+    // [row][k / 32][plane][32] bf16 and the number of 32-deep K tiles per row
     const void* b3;
-    uint32_t ts3;
+    int kt3;
 };
 
 struct GemmProb {
@@ -132,8 +131,7 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st);
 // split_mode(): knob "mfma_split" (default 1); 0 = the exact-fp32 v_mfma_f32_32x32x2_f32 kernels.
 int split_mode();
 // Pre-split images of the weight matrices (built by marl_pack_weights next to their fp32 copies):
-// a matrix [rows][ld] fp32 with k valid columns -> [ceil(k / 32)][rows][3][32] bf16, zero-padded
-// (tile-major: the 128 rows of a B tile are ONE contiguous 24 KB block, fetched in full lines).
+// a matrix [rows][ld] fp32 with k valid columns -> [rows][ceil(k / 32)][3][32] bf16, zero-padded.
 size_t split_image_floats(int rows, int k);  // size of an image in units of 4 bytes
 struct SplitDesc {
     const float* src;  // [rows][ld]
@@ -150,10 +148,8 @@ int launch_split_weights(const SplitBatch& b, hipStream_t st);
 // workspace; the launchers look the B operands of a product up in it
 void split_registry_reset();
 void split_registry_add(const float* base, int rows, int ld, int k, const void* image);
-// (*done = 0: a B operand is no registered weight matrix - the caller takes the fp32 kernel)
-int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st,
-                         int* done);
-int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStream_t st, int* done);
+int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st);
+int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStream_t st);
 int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
                          int64_t stride, int ni, int nj, int64_t rows, int64_t rows_per_split,
                          float* csum, dim3 grid, int gx, int gy, int gz, hipStream_t st);

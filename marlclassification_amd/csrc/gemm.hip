@@ -969,9 +969,8 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
                     batch.p[i].nseg > 1 ? batch.p[i].seg[1].k : 0, batch.p[i].accumulate,
                     batch.p[i].bias != nullptr, batch.p[i].seg[0].lda, batch.p[i].ldc);
     prof_before(1, st);
-    int split_done = 0;
-    if (split_mode()) MARL_TRY(launch_gemm_nt_split(batch, max_m, max_n, blocks128, st, &split_done));
-    if (split_done) {
+    if (split_mode()) {
+        MARL_TRY(launch_gemm_nt_split(batch, max_m, max_n, blocks128, st));
     } else if (blocks128 >= tune_get("nt_min_blocks128", 256) && max_n >= 96) {
         const int g = gemm_groups();
         dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
@@ -1054,10 +1053,9 @@ int launch_gemm_lstm(const GemmBatch& batch, hipStream_t st) {
     const int g = gemm_groups();
     dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 32), (unsigned)batch.count);
     prof_before(0, st);
-    int split_done = 0;
-    if (split_mode()) MARL_TRY(launch_gemm_lstm_split(batch, max_m, max_n, st, &split_done));
-    if (split_done) {
-    } else if (g == 2)
+    if (split_mode())
+        MARL_TRY(launch_gemm_lstm_split(batch, max_m, max_n, st));
+    else if (g == 2)
         MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 2>(grid, batch, st)));
     else
         MARL_TRY((launch_nt_variant<128, 128, 4, 1, true, 1>(grid, batch, st)));
