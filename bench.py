@@ -46,18 +46,35 @@ OTHER = {
                 nlb=384, nla=384, actions=[[4, 0], [-4, 0], [0, 4], [0, -4]]), 64, 32,
            (3, 1024, 1024), 32, "synthetic 1024x1024, 64 agents, 32 steps, f=32"),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+# fp32 products on the bf16 pipe (gemm_split.hip): six bf16 MFMA products per fp32 product
+PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 # kernel classes of marl_profile_begin (include/marl_hip.h)
 CLASSES = {
-    0: "gemm_nt_kernel<128,128,4,1,LSTM> (belief+action LSTM cells, fused cell epilogue)",
-    1: "gemm_nt_kernel (activations x weights: batched heads, dX / dU products, in-loop W_hh)",
-    2: "gemm_tn_kernel (weight gradients: contraction over all Ns*R rows)",
+    0: "gemm_nt[_split]_kernel<LSTM> (belief+action LSTM cells, fused cell epilogue)",
+    1: "gemm_nt[_split]_kernel (activations x weights: batched heads, dX / dU products, in-loop W_hh)",
+    2: "gemm_tn[_split]_kernel (weight gradients: contraction over all Ns*R rows)",
     3: "cnn_fwd_kernel (gather + conv/GroupNorm/SiLU stack, one launch per step)",
     4: "panel_fwd/bwd_kernel (message encoder / decoder, policy hidden layer, per step)",
     5: "cnn_dgrad + cnn_wgrad kernels (CNN backward, batched over all steps)",
 }
+
+
+def csrc_sha256() -> str:
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h): ties PMC-derived numbers to a build."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "marlclassification_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def cnn_shapes(cfg: dict):
@@ -161,7 +178,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many images in all, N / world per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-only", action="store_true")
     ap.add_argument("--torch-rng", action="store_true",
@@ -169,6 +188,8 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true", help="replay the iteration as a captured hipGraph")
     ap.add_argument("--config", choices=["c3"] + sorted(OTHER), default="c3")
     args = ap.parse_args()
+    if args.graph and args.rollout_only:
+        ap.error("--graph replays the whole training iteration: not with --rollout-only")
     global C3, NA, NS, IMG
     workload = "RESISC45 256x256x3, 16 agents, 16 steps, f=12, README dims (configs[2])"
     if args.config != "c3":
@@ -215,6 +236,10 @@ def main() -> None:
     spec = eng.spec
     is_c3 = args.config == "c3"
     nb = args.batch
+    if args.global_batch:
+        if args.global_batch % world != 0:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by the world size {world}")
+        nb = args.global_batch // world
     eng.configure(NA, nb, NS, IMG)
     hook = GradAllReduce(world) if distributed else None
     fa = FusedA2C(eng, flat, LR, GAMMA, allreduce=hook, use_graph=args.graph)
@@ -281,12 +306,20 @@ def main() -> None:
     f_fwd, by_fwd, by_train, cls_flops = algorithmic_work(C3, IMG[0])
     steps_per_iter_gpu = nb * NA * NS
     sweep = {}
+
+    def sweep_step():
+        # the per-class events are recorded by the launchers: a hipGraph replay runs none of
+        # them, so the sweep iterations are launched eagerly whatever the timed loop did
+        if not args.graph:
+            return one_step()
+        state["out"], state["scalars"] = fa.iteration(img, y, draw_episode_device(eng, rng_seed, 1 << 30))
+
     for c in CLASSES:
         if args.rollout_only and c in (2, 5):
             continue
         if rank == 0:
             lib.marl_profile_begin(c, 4096)
-        one_step()
+        sweep_step()
         if rank == 0:
             tot, cnt = C.c_double(0), C.c_int(0)
             lib.marl_profile_end(C.byref(tot), C.byref(cnt))
@@ -305,10 +338,19 @@ def main() -> None:
         if args.rollout_only and dom not in fwd_only:
             dom_flops /= 3.0
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        # the matrix classes 0-2 run fp32 products as six bf16 MFMA products (mfma_split, default):
+        # their pipe is the bf16 one, priced in fp32-equivalent FLOPs = 2.5 PF / 6; with the knob
+        # off (and for the CNN / panel classes, which use v_mfma_f32_*) the fp32-MFMA peak applies
+        split_on = lib.marl_tune_get(b"mfma_split", 1) != 0
+        peak = PEAK_F32_VIA_BF16X6_TFLOPS if (split_on and dom in (0, 1, 2)) else PEAK_F32_MFMA_TFLOPS
         roofline = {
             "kernel": CLASSES[dom],
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "peak_note": ("fp32-equivalent: fp32 operands split into three bf16 terms, six bf16 MFMA "
+                          "products per fp32 product = 2500 / 6 TF; against the 157.3 TF of "
+                          "v_mfma_f32_32x32x2_f32 this is frac %.3f" % (achieved / PEAK_F32_MFMA_TFLOPS))
+                         if peak != PEAK_F32_MFMA_TFLOPS else "v_mfma_f32_* (exact fp32 MFMA)",
             "avg_launch_us": round(dom_ms * 1e3 / max(1, dom_n), 2), "launches": dom_n,
             "share_of_iteration": round(dom_ms * 1e-3 / t_iter, 4),
             "traffic": None,
@@ -323,19 +365,24 @@ def main() -> None:
                 "achieved": round(max(t_mfma, t_hbm) / t_iter, 4),
                 "bound": "mfma" if t_mfma >= t_hbm else "hbm",
                 "note": "max(t_hbm, t_mfma) / t_measured with algorithmic FLOPs (3x forward) and "
-                        "bytes per agent-env-step from SURVEY 8(d)",
+                        "bytes per agent-env-step from SURVEY 8(d); t_mfma is priced at the EXACT-fp32 "
+                        "MFMA peak (157.3 TF) whatever pipe the products run on",
             },
         }
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
         # THIS round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if they cover it
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if nb == 256 and is_c3 and os.path.exists(tpath):
+        # (only if they were taken from THIS library: the file carries the sha256 of csrc/*.hip|*.h)
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if nb == 256 and is_c3 and not args.rollout_only and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
                 tj = json.load(f)
             ent = tj.get(str(dom))
-            if ent:
+            if ent and tj.get("src_sha256") == csrc_sha256():
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r02_traffic.json)"
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r03_traffic.json, sources match)"
+            elif ent:
+                roofline["traffic_unit"] = ("null: profiles/r03_traffic.json was measured on other kernel "
+                                            "sources (sha256 differs)")
     if distributed:
         dist.barrier()
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
@@ -349,13 +396,16 @@ def main() -> None:
             "value": round(value, 1), "unit": "agent-env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {
                 "workload": workload + "; full train iteration: rollout + A2C loss + BPTT "
                             "backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
                 "batch_per_gpu": nb, "global_batch": nb * world,
                 "parallelism": f"dp{world}",
                 "rng": "torch" if args.torch_rng else "library (Philox4x32-10)",
+                "matrix_products": "fp32 operands, 3-term bf16 split, 6 bf16 MFMA products, fp32 accumulate "
+                                   "(gemm_split.hip; MARL_MFMA_SPLIT=0: v_mfma_f32_32x32x2_f32)",
                 "launch": "hipGraph replay" if args.graph else "eager",
             },
             "roofline": roofline, "cpu_baseline": cpu,

@@ -262,8 +262,14 @@ int marl_cnn_wgrad(const float* dz, const void* img, int img_u8, const int32_t* 
 size_t marl_cnn_wgrad_scratch(int64_t rows, int cin, int cout, int hin, int groups, int first);
 
 /* Perf-experiment hook: overrides an internal tuning knob (same names as the MARL_<KEY>
- * environment variables, lower case, e.g. "wgrad_rb"); tools/ and tests only. */
+ * environment variables, lower case, e.g. "wgrad_rb", "mfma_split"); tools/ and tests only.
+ * Several knobs change the LAYOUT of the episode workspace (tile plans, split-K targets,
+ * mfma_split ...): marl_workspace_sizes() must be asked again and the workspace re-allocated
+ * after such a call - the library never sees the size of the buffer it is handed.  (The Python
+ * wrapper marlclassification_amd.engine.tune() drops every cached workspace.) */
 int marl_tune(const char* key, int value);
+/* current value of a knob (marl_tune value, else MARL_<KEY>, else dflt) */
+int marl_tune_get(const char* key, int dflt);
 
 /* Measurement hook (bench.py roofline): time every launch of one kernel class with HIP
  * events recorded on the launch stream.  class 0 = fused LSTM-cell GEMM, 1 = plain NT GEMM,

@@ -68,7 +68,7 @@ EXPORTS = (
     "marl_a2c_loss_fwd_bwd marl_adam_step marl_step_forward marl_gemm_nt marl_gemm_tn "
     "marl_gemm_tn_scratch marl_gemm_nt_weights marl_gemm_weight_image_bytes marl_ln_silu_fwd marl_debug_buffer "
     "marl_profile_begin marl_profile_end marl_normalize_positions "
-    "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_draw_episode "
+    "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_tune_get marl_draw_episode "
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
     "marl_graph_destroy"
 ).split()
@@ -119,12 +119,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_cnn_wgrad_scratch.restype = _sz
     lib.marl_cnn_wgrad_scratch.argtypes = [_i64, _i, _i, _i, _i, _i]
     lib.marl_tune.argtypes = [C.c_char_p, _i]
+    lib.marl_tune_get.argtypes = [C.c_char_p, _i]
     lib.marl_profile_begin.argtypes = [_i, _i]
     lib.marl_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(_i)]
     lib.marl_debug_buffer.argtypes = [_cfgp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("marl_abi_version",):
+        if fn.restype is C.c_int and name not in ("marl_abi_version", "marl_tune_get"):
             fn.restype = _i
 
 

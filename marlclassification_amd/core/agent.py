@@ -18,6 +18,8 @@ class AgentOutput:
 
 
 class MultiAgent:
+    _instances = 0
+
     def __init__(self, nb_agents: int, model: ModelsWrapper) -> None:
         self.__nb_agents = nb_agents
         self.__model = model
@@ -30,6 +32,8 @@ class MultiAgent:
         # seed and a call counter); False: torch draws the Exp(1) tensor
         self.device_rng = True
         self.__calls = 0
+        MultiAgent._instances += 1
+        self.__stream_id = MultiAgent._instances  # own generator stream (with the rank: see act)
 
     def reset(self, batch_size: int) -> None:
         self.__hidden = self.__model.random_first_state(len(self), batch_size)
@@ -49,7 +53,13 @@ class MultiAgent:
         if self.fixed_noise is not None:
             noise, self.fixed_noise = self.fixed_noise, None
         elif self.device_rng:
-            rng = (th.initial_seed(), (1 << 40) + self.__calls)  # offsets apart from the episodes'
+            import os
+
+            from ..parallel import shard_seed
+
+            key = shard_seed(th.initial_seed() & 0xFFFFFFFFFFFF, int(os.environ.get("RANK", "0")))
+            key = (key * 1_000_003 + (1 << 20) + self.__stream_id) & ((1 << 63) - 1)
+            rng = (key, (1 << 40) + self.__calls)  # offsets apart from the episodes'
             self.__calls += 1
         else:
             noise = th.empty(na, nb, model.nb_action, device=observation.device).exponential_(1.0)

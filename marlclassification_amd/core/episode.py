@@ -53,6 +53,8 @@ class _EpisodeFunction(th.autograd.Function):
 
 
 class EpisodeSampler:
+    _instances = 0
+
     def __init__(self, agents: MultiAgent, env: Environment, nb_step: int) -> None:
         self.__agents = agents
         self.__env = env
@@ -66,6 +68,11 @@ class EpisodeSampler:
         self.device_rng = True
         self.__episodes = 0
         self.__rng_seed: Optional[int] = None
+        # every sampler is its own stream of the generator: the key mixes torch's seed with the
+        # rank (shards draw different positions / states / noise under the usual identical
+        # th.manual_seed on all ranks) and a per-process sampler id
+        EpisodeSampler._instances += 1
+        self.__stream_id = EpisodeSampler._instances
 
     @property
     def nb_step(self) -> int:
@@ -78,6 +85,15 @@ class EpisodeSampler:
     @property
     def env(self) -> Environment:
         return self.__env
+
+    def draw_key(self, seed: int) -> int:
+        """Generator key of this sampler's draws: (torch seed, rank, sampler id)."""
+        import os
+
+        from ..parallel import shard_seed
+
+        rank = int(os.environ.get("RANK", "0"))
+        return (shard_seed(seed & 0xFFFFFFFFFFFF, rank) * 1_000_003 + self.__stream_id) & ((1 << 63) - 1)
 
     def prepare(self, img_batch: th.Tensor) -> Tuple[HipEngine, th.Tensor, EpisodeDraws]:
         """Everything before the kernels: device transfer, engine configuration, weight
@@ -99,7 +115,7 @@ class EpisodeSampler:
             seed = th.initial_seed()
             if seed != self.__rng_seed:  # th.manual_seed() restarts the episode counter
                 self.__rng_seed, self.__episodes = seed, 0
-            d = draw_episode_device(eng, seed, self.__episodes)
+            d = draw_episode_device(eng, self.draw_key(seed), self.__episodes)
             self.__episodes += 1
             env.place(img, na, positions=d.pos0)
             return eng, img, d

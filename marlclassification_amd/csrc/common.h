@@ -495,6 +495,7 @@ struct PanelBwdProb {
 };
 int panel_bwd_blocks(int m);
 int panel_chain_blocks(int na, int nb);  // workgroups of a by_batch launch
+int panel_chain_by_batch(int na);        // batch elements a chained workgroup owns (panel rows / na)
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st);
 
 // ---------------------------------------------------------------------------

@@ -795,7 +795,7 @@ static int step_chain(const Ctx& c, int t) {
     pb.count = 2;
     PanelFwdProb& pe = pb.p[0];
     fill_enc_prob(c, t, pe);
-    pe.by_batch = 16 / d.na;
+    pe.by_batch = panel_chain_by_batch(d.na);
     pe.g_na = d.na;
     pe.g_nb = d.nb;
     if (t + 1 < d.ns) {
@@ -1263,7 +1263,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
             }
             if (chain) {
                 // decoder(t) -> mean -> encoder(t-1) -> dh_t -> belief cell(t-1), one launch
-                pd.by_batch = 16 / d.na;
+                pd.by_batch = panel_chain_by_batch(d.na);
                 pd.g_na = d.na;
                 pd.g_nb = d.nb;
                 if (t > 0) {
@@ -2005,6 +2005,8 @@ int marl_tune(const char* key, int value) {
     if (!key) return MARL_EINVAL;
     return tune_set(key, value);
 }
+
+int marl_tune_get(const char* key, int dflt) { return key ? tune_get(key, dflt) : dflt; }
 
 int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out,
                      int ldo, float* stats, int m, int n, void* stream) {

@@ -902,6 +902,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
 
 int panel_bwd_blocks(int m) { return (int)cdiv(m, kPanelRows); }
 int panel_chain_blocks(int na, int nb) { return na >= 1 && na <= kPanelRows ? (int)cdiv(nb, kPanelRows / na) : 0; }
+int panel_chain_by_batch(int na) { return na >= 1 && na <= kPanelRows ? kPanelRows / na : 0; }
 
 int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     int waves = 8, pmax = 0, nmax = 0, prm = 0;

@@ -123,6 +123,19 @@ class ModelSpec:
 
 _U64 = (1 << 64) - 1
 
+# Layout-affecting knobs (marl_tune: tile plans, split-K targets, mfma_split ...) change the sizes
+# of regions INSIDE the episode workspace.  The library recomputes the layout on every call but
+# never sees the workspace size, so a buffer allocated before a knob changed must not be reused:
+# ``tune`` bumps this epoch and every HipEngine drops its cached workspaces when it differs.
+_tune_epoch = 0
+
+
+def tune(key: str, value: int) -> None:
+    """marl_tune + invalidation of every engine's cached workspaces (set knobs through this)."""
+    global _tune_epoch
+    check(_lib.load().marl_tune(key.encode(), int(value)))
+    _tune_epoch += 1
+
 
 def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
@@ -167,6 +180,7 @@ class HipEngine:
         self._cfg_key: Optional[Tuple] = None
         self.cfg: Optional[MarlConfig] = None
         self._packed_version: Optional[int] = None
+        self._tune_seen = _tune_epoch
         # what the last training rollout left behind for backward: the episode workspace holds
         # its activations, `_fwd_img` keeps its image batch alive (the first convolution's weight
         # gradient re-gathers the patches), `fwd_generation` lets callers detect a stale backward
@@ -197,6 +211,10 @@ class HipEngine:
         return self._wws
 
     def episode_ws(self, train: bool) -> th.Tensor:
+        if self._tune_seen != _tune_epoch:  # a layout knob changed: sizes may have moved
+            self._ews.clear()
+            self._fwd_img = None
+            self._tune_seen = _tune_epoch
         key = (self._cfg_key, train)
         ws = self._ews.get(key)
         if ws is None:

@@ -146,6 +146,7 @@ class FusedA2C:
         if self._graph is None or self._graph[0] != key:
             if self._graph is not None:
                 eng.lib.marl_graph_destroy(self._graph[1])
+                self._graph = None
             # this call runs eagerly (one-off set-up inside the library happens here) ...
             eager = self.iteration(img, y, draw_episode_device(eng, seed, offset))
             offset += 1  # ... and the graph captured below starts at the NEXT iteration
@@ -169,17 +170,35 @@ class FusedA2C:
                              self.flat.exp_avg_sq, 1, self.lr, counters=cnt)
                     eng.pack(self._pviews)
                     eng.counters_tick(cnt, self.lr)
-                finally:
-                    handle = eng.graph_end()
-            self._graph = (key, handle, stream, (out, draws, cnt, scalars))
+                except BaseException:
+                    # the capture is invalid now: end it, drop whatever that reports, and let the
+                    # ROOT cause propagate (no stale graph is left behind: self._graph is None)
+                    try:
+                        eng.graph_end()
+                    except Exception:
+                        pass
+                    raise
+                handle = eng.graph_end()
+            # what the device-side counter block holds after the capture: the state the FIRST replay
+            # expects (generator offset, optimiser step, learning rate)
+            self._graph = (key, handle, stream, (out, draws, cnt, scalars),
+                           {"offset": offset, "step": self.flat.step + 1, "cap_lr": self.lr})
             return eager
-        _, handle, stream, (out, _draws, _cnt, scalars) = self._graph
+        _, handle, stream, (out, _draws, cnt, scalars), expect = self._graph
         stream.wait_stream(th.cuda.current_stream(eng.device))
         with th.cuda.stream(stream):
+            # eager iterations in between, another offset or a changed learning rate: the device
+            # counters are re-synchronised with the host's view before the replay
+            # (the tick at the end of the captured graph recomputes the step size with the learning
+            # rate of the CAPTURE: after a change of self.lr the counters are set before every replay)
+            if (expect["offset"] != offset or expect["step"] != self.flat.step + 1 or
+                    expect["cap_lr"] != self.lr):
+                eng.counters_set(cnt, offset, self.flat.step + 1, self.lr)
             eng.graph_launch(handle)
         th.cuda.current_stream(eng.device).wait_stream(stream)
         self.flat.step += 1
         eng.fwd_generation += 1
+        expect.update(offset=offset + 1, step=self.flat.step + 1)
         return out, scalars
 
     def iteration(self, img: th.Tensor, y: th.Tensor, draws: EpisodeDraws) -> Tuple[EpisodeTensors, th.Tensor]:

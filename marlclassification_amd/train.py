@@ -11,12 +11,12 @@ from os.path import exists, isdir, join
 from typing import Dict, Optional
 
 import torch as th
-from torch.utils.data import DataLoader, Subset
+from torch.utils.data import DataLoader, Sampler
 
 from .config import MainConfig, ModelConfig, TrainConfig
 from .core import EpisodeSampler
-from .data import DevicePrefetcher, ImageFolderU8, SyntheticImages
-from .parallel import GradAllReduce, shard_bounds
+from .data import DevicePrefetcher, ImageFolderU8, ResidentLoader, SyntheticImages
+from .parallel import GradAllReduce
 from .training import Trainer
 
 
@@ -54,19 +54,62 @@ def _dataset(model_config: ModelConfig, train_config: TrainConfig):
     return dataset
 
 
-class _Sharded:
-    """Every rank sees the same batches (same seed) and keeps its contiguous shard."""
+class ShardedBatchSampler(Sampler):
+    """Batches of dataset INDICES for one rank.  Every rank derives the same shuffled order of
+    the same index list from (seed, epoch) and takes its contiguous slice of every global batch,
+    so a rank only decodes the images it trains on (the reference has one process and 6 loader
+    workers, train.py:91-107; slicing after the decode would repeat the host work on every
+    rank).  The last, smaller global batch is trimmed to a multiple of the world size."""
 
-    def __init__(self, loader: DataLoader, rank: int, world: int) -> None:
-        self.loader, self.rank, self.world = loader, rank, world
+    def __init__(self, indices, global_batch: int, rank: int, world: int, shuffle: bool, seed: int) -> None:
+        if global_batch % world != 0:
+            raise ValueError(f"batch size {global_batch} is not divisible by the world size {world}")
+        self.indices = list(indices)
+        self.global_batch, self.rank, self.world = global_batch, rank, world
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
 
-    def __iter__(self):
-        for x, y in self.loader:
-            n = (x.shape[0] // self.world) * self.world
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def _batches(self):
+        order = self.indices
+        if self.shuffle:
+            g = th.Generator().manual_seed(self.seed * 1_000_003 + self.epoch)
+            order = [self.indices[i] for i in th.randperm(len(order), generator=g).tolist()]
+        for lo in range(0, len(order), self.global_batch):
+            chunk = order[lo: lo + self.global_batch]
+            n = (len(chunk) // self.world) * self.world
             if n == 0:
                 continue
-            lo, hi = shard_bounds(n, self.rank, self.world)
-            yield x[lo:hi], y[lo:hi]
+            per = n // self.world
+            yield chunk[self.rank * per: (self.rank + 1) * per]
+
+    def __iter__(self):
+        return self._batches()
+
+    def __len__(self) -> int:
+        full, rest = divmod(len(self.indices), self.global_batch)
+        return full + (1 if rest >= self.world else 0)
+
+
+def loader_workers(dataset) -> int:
+    """Decode processes per rank: the reference uses 6 (train.py:95); MARL_LOADER_WORKERS
+    overrides; in-memory synthetic data needs none."""
+    if isinstance(dataset, SyntheticImages):
+        return 0
+    env = os.environ.get("MARL_LOADER_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    return max(0, min(6, (os.cpu_count() or 1) - 1))
+
+
+def resident_fits(dataset) -> bool:
+    """Keep the decoded uint8 image set in HBM (data.ResidentLoader) when it is an image
+    folder no larger than MARL_RESIDENT_GB (default 64; 0 = always stream from the loader)."""
+    if not isinstance(dataset, ImageFolderU8) or len(dataset) == 0:
+        return False
+    budget = float(os.environ.get("MARL_RESIDENT_GB", "64")) * 1e9
+    return ResidentLoader.nbytes(dataset, len(dataset)) <= budget
 
 
 def train_main(main_config: MainConfig, model_config: ModelConfig, train_config: TrainConfig,
@@ -87,12 +130,21 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and world > 1
+    # launched by torch.distributed.run (any world size: one rank still goes through RCCL, so
+    # the exact command line of a multi-GPU run is what a 1-GPU box tests)
+    distributed = "RANK" in os.environ
     device = th.device("cuda", local_rank)
     th.cuda.set_device(device)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=device)
+    # one base seed for the run (MARL_SEED, default 0): identical initial weights and data order on
+    # every rank; the episode draws mix the rank in (core/episode.py), so shards draw differently
+    base_seed = int(os.environ.get("MARL_SEED", "0"))
+    th.manual_seed(base_seed)
+    if rank == 0:
+        print(f"seed {base_seed}, world size {world}", flush=True)
 
     nn_models, marl_m, env = model_config.build_marl(main_config.nb_agent)
     dataset = _dataset(model_config, train_config)
@@ -105,24 +157,35 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
         for p in nn_models.parameters():
             dist.broadcast(p.data, src=0)
 
-    g = th.Generator().manual_seed(0)  # same split and shuffle on every rank
+    g = th.Generator().manual_seed(base_seed)  # same split on every rank
     idx = th.randperm(len(dataset), generator=g)
     cut = int(0.85 * idx.shape[0])
-    loaders = []
-    for part in (idx[:cut].tolist(), idx[cut:].tolist()):
-        dl = DataLoader(Subset(dataset, part), batch_size=train_config.batch_size, shuffle=True,
-                        num_workers=0, drop_last=False, pin_memory=True,
-                        generator=th.Generator().manual_seed(1))
-        dl = _Sharded(dl, rank, world) if distributed else dl
+    loaders, samplers = [], []
+    workers = loader_workers(dataset)
+    resident = resident_fits(dataset)
+    if rank == 0:
+        print(f"input pipeline: {'HBM-resident uint8 image set' if resident else 'streamed'}, "
+              f"{workers} decode processes per rank", flush=True)
+    for k, part in enumerate((idx[:cut].tolist(), idx[cut:].tolist())):
+        bs = ShardedBatchSampler(part, train_config.batch_size, rank, world, shuffle=True,
+                                 seed=base_seed + 1 + k)
+        samplers.append(bs)
+        if resident:  # decoded once (1/world per rank), then batches are row gathers in HBM
+            loaders.append(ResidentLoader(dataset, part, bs, device, workers=workers, rank=rank, world=world))
+            continue
+        dl = DataLoader(dataset, batch_sampler=bs, num_workers=workers, pin_memory=True,
+                        persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
         loaders.append(DevicePrefetcher(dl, device))  # upload of batch i+1 overlaps step i
 
     sampler = EpisodeSampler(marl_m, env, main_config.step)
     trainer = Trainer(nn_models, marl_m.nb_class, train_config.learning_rate, train_config.gamma,
                       metric_logger=metric_logger if rank == 0 else None,
                       allreduce=GradAllReduce(world) if distributed else None,
-                      exact_standardize_group=(dist.group.WORLD if distributed and exact_standardize
-                                               else None))
+                      exact_standardize_group=(dist.group.WORLD if distributed and world > 1 and
+                                               exact_standardize else None))
     for e in range(train_config.nb_epoch):
+        for bs in samplers:
+            bs.set_epoch(e)
         trainer.train_epoch(loaders[0], e, sampler)
         conf = trainer.eval_epoch(loaders[1], e, sampler)
         if distributed:

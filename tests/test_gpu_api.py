@@ -208,7 +208,7 @@ def test_train_main_cli_end_to_end(device, tmp_path):
     assert any(not th.equal(sd[k], sd0[k]) for k in sd), "weights did not change between epochs"
 
 
-def test_cli_train_test_infer_on_an_image_folder(device, tmp_path):
+def test_cli_train_test_infer_on_an_image_folder(device, tmp_path, monkeypatch, capsys):
     """the reference's three modes end to end on a (tiny) image-folder dataset
     laid out like the reference's resources directory: ``train`` (dataset resolved under
     ``downloaded/mnist_png/all_png``, per-epoch state dicts, confusion-matrix PNG, step GIF),
@@ -238,6 +238,16 @@ def test_cli_train_test_infer_on_an_image_folder(device, tmp_path):
     assert (out / "confusion_matrix_epoch_0_eval.png").exists()
     assert (out / "animated_gif.gif").exists() and (out / "pred_step_3.png").exists()
     assert json.loads((out / "class_to_idx.json").read_text()) == {"class0": 0, "class1": 1, "class2": 2}
+    # the same command streamed through DataLoader workers instead of the HBM-resident image set
+    monkeypatch.setenv("MARL_RESIDENT_GB", "0")
+    monkeypatch.setenv("MARL_LOADER_WORKERS", "2")
+    out_s = tmp_path / "run_streamed"
+    main((f"{common} train --ft-extr mnist --f 6 --img-size 28 --nb-class 3 --nb 32 --na 32 --nm 8 "
+          f"--nmo 12 --nd 8 --nlb 48 --nla 48 --batch-size 8 --nb-epoch 1 --lr 1e-3 --res-folder {res} "
+          f"-o {out_s}").split())
+    assert (out_s / "models" / "nn_models_epoch_0.pt").exists()
+    assert "streamed" in capsys.readouterr().out
+    monkeypatch.delenv("MARL_RESIDENT_GB")
     # a wrong resources folder is an error, not a silent synthetic run
     with pytest.raises(NotADirectoryError):
         main((f"{common} train --ft-extr mnist --f 6 --img-size 28 --nb-class 3 --res-folder {tmp_path / 'nope'} "

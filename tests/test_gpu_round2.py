@@ -66,9 +66,27 @@ def _check_against_oracle(eng, cfg, device, params, img, y, inp, ns, img_dev=Non
     if free_running:
         free = eng.episode_forward(img_dev, *args, None, False)
         nflip = (free.step_actions.cpu() != tr.step_actions).sum().item()
-        assert nflip <= max(1, tr.step_actions.numel() // 2000), f"{nflip} sampled actions differ"
+        allowed = flip_budget(tr, inp, errs["logp"])
+        FLIPS.append({"numel": tr.step_actions.numel(), "flips": nflip, "allowed": allowed})
+        assert nflip <= allowed, f"{nflip} sampled actions differ (budget {allowed})"
     errs["grad_rel"] = worst
     return errs
+
+
+FLIPS = []  # (numel, flips, allowed) of every oracle-only free-running comparison of this session
+
+
+def flip_budget(tr, inp, logp_err):
+    """How many sampled indices MAY differ from the oracle's: a sample is argmax_k p_k / q_k
+    (core/agent.py:53-55); it can only flip where the two largest ratios are closer than the
+    relative error of the probabilities.  Counted on the oracle's own probabilities and noise
+    with 4x the measured log-prob error (>= 2e-6) as that relative error: 0 for almost every case."""
+    eps = 4.0 * max(logp_err, 5e-7)
+    if not hasattr(tr, "step_probs") or tr.step_probs is None:
+        return 0
+    ratio = tr.step_probs.double() / inp.q.double().view_as(tr.step_probs)
+    top2 = ratio.topk(2, dim=-1).values
+    return int(((top2[..., 0] - top2[..., 1]) <= eps * top2[..., 0]).sum().item())
 
 
 # ---- (a) the benched size: B = 256, R = 4096 rows, the 128x128 / grouped / split-K plans -----
@@ -460,7 +478,8 @@ def test_two_rank_hip_trainer_matches_big_batch_update(device, exact):
 # ---- achieved errors per fixture (recorded for DESIGN.md) ------------------------------------------
 def test_record_achieved_errors(device):
     """Not a tolerance test: measures the achieved max |error| of every fixture against the
-    reference's goldens and writes them to gpurun_out/r02_achieved_errors.json."""
+    reference's goldens and writes them to gpurun_out/r03_achieved_errors.json (with the
+    sampled-index flips of the oracle-only cases that ran before it in this session)."""
     rec = {}
     for tag in ("g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt", "g4_resisc_b2"):
         g = Golden(tag)
@@ -492,12 +511,15 @@ def test_record_achieved_errors(device):
             upd, ref_upd = flat_p.cpu() - ref_before, ref_after - ref_before
             e["adam_update_err_over_lr"] = ((upd[big] - ref_upd[big]).abs().max() / g.lr).item()
         rec[tag] = e
+    rec["oracle_only_free_running"] = {"cases": len(FLIPS), "samples": sum(f["numel"] for f in FLIPS),
+                                       "flips": sum(f["flips"] for f in FLIPS),
+                                       "budget": sum(f["allowed"] for f in FLIPS)}
     path = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "r02_achieved_errors.json"), "w") as f:
+        with open(os.path.join(path, "r03_achieved_errors.json"), "w") as f:
             json.dump(rec, f, indent=1)
     except OSError:
         pass
     print(json.dumps(rec))
-    assert all(r["pos_equal"] for r in rec.values())
+    assert all(r["pos_equal"] for r in rec.values() if "pos_equal" in r)

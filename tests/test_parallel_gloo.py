@@ -102,3 +102,58 @@ def test_shard_bounds_and_seeds():
     with pytest.raises(ValueError):
         shard_bounds(10, 0, 4)
     assert len({shard_seed(42, r) for r in range(8)}) == 8
+
+
+# ---- input pipeline: index-sharded sampler and the decode-once resident image set -----------------
+def _resident_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    th.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marlclassification_amd.data import ResidentLoader, SyntheticImages
+    from marlclassification_amd.train import ShardedBatchSampler
+
+    ds = SyntheticImages(37, 3, 8, 5, seed=3)
+    part = th.randperm(37, generator=th.Generator().manual_seed(1))[:31].tolist()  # odd: padded shards
+    bs = ShardedBatchSampler(part, 8, rank, world, shuffle=True, seed=2)
+    rl = ResidentLoader(ds, part, bs, "cpu", workers=0, rank=rank, world=world, chunk=4)
+    got = []
+    for e in range(2):
+        bs.set_epoch(e)
+        got.append([(x.numpy().copy(), y.numpy().copy()) for x, y in rl])
+    out_q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resident_image_set_equals_the_streamed_batches():
+    """Each rank decodes half of the images, the all-gather rebuilds the set, and the batches a
+    rank then gathers are exactly the images its index slices name (two epochs, two shuffles)."""
+    from marlclassification_amd.data import SyntheticImages
+    from marlclassification_amd.train import ShardedBatchSampler
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resident_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ds = SyntheticImages(37, 3, 8, 5, seed=3)
+    part = th.randperm(37, generator=th.Generator().manual_seed(1))[:31].tolist()
+    for rank in range(2):
+        bs = ShardedBatchSampler(part, 8, rank, 2, shuffle=True, seed=2)
+        for e in range(2):
+            bs.set_epoch(e)
+            want = list(bs)
+            assert len(want) == len(res[rank][e]) == len(bs)
+            for idx, (x, y) in zip(want, res[rank][e]):
+                assert th.equal(th.from_numpy(x), ds.x[idx]) and th.equal(th.from_numpy(y), ds.y[idx])
+    # the two ranks' slices of one global batch are disjoint and cover it
+    a = ShardedBatchSampler(part, 8, 0, 2, True, 2)
+    b = ShardedBatchSampler(part, 8, 1, 2, True, 2)
+    for ia, ib in zip(a, b):
+        assert not set(ia) & set(ib) and len(ia) == len(ib)
