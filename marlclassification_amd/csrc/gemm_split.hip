@@ -63,6 +63,24 @@ __device__ __forceinline__ void split_store4(char* dst, int plane, float a, floa
     *reinterpret_cast<uint2*>(dst + 2 * plane) = make_uint2(a2, b2);
 }
 
+// Staging maps (thread chunk c -> tile row / piece) chosen for the LDS STORE banking (32 banks,
+// MI355X_MICROARCH.md LDS table): with 80-byte rows a 16-lane ds_write_b64 group that covers rows
+// r, r + 1 hits four banks twice, rows r, r + 4 (320 B = 16 banks apart) none - measured before
+// the remap: SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE in the NT kernels, every store 2-way.
+// fp32 tiles: chunk c = 8 bytes (four k) of row stage_row(c), piece c % 8.
+__device__ __forceinline__ constexpr int stage_row(int c) {
+    return (c >> 6) * 8 + ((c >> 4) & 3) + 4 * ((c >> 3) & 1);
+}
+// pre-split image tiles (16-byte pieces, four per row and plane; RW rows per wave): lanes 4u..4u+3
+// hold one (row, plane) unit; units 2v, 2v + 1 of an 8-lane ds_write_b128 group are rows r, r + 4
+template <int RW>
+__device__ __forceinline__ void image_unit(int c, int& row, int& plane) {
+    const int wave = (c & 255) >> 6, u = ((c & 63) >> 2) + 16 * (c >> 8);
+    const int v = u >> 1, rb = v % (RW / 2);
+    plane = v / (RW / 2);
+    row = wave * RW + (rb >> 2) * 8 + (rb & 3) + 4 * (u & 1);
+}
+
 // Matrix phase of one staged tile.  al / bl: this lane's fragment address in plane 0 of the A / B
 // image (row = tile row of the wave + lane % 32, k = (lane / 32) * 8); planes APL / BPL bytes apart.
 // All fragments of a 16-deep step are read first, then the MFMAs walk the accumulators round
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
     auto set_seg_a = [&](int sg) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            int gm = m0 + (tid + 256 * i) / KC;
+            int gm = m0 + stage_row(tid + 256 * i);
             gm = gm < M ? gm : M - 1;
             aof[i] = ((uint32_t)gm * (uint32_t)P.seg[sg].lda + (uint32_t)koff) * 4u;
         }
@@ -169,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
 #pragma unroll
         for (int i = 0; i < (BPRE ? B3_CH : B_CH); ++i) {
             const int c = tid + 256 * i;
-            const int row = BPRE ? c / 12 : c / KC;
+            int row = stage_row(c), plane = 0;
+            if (BPRE) image_unit<BN / 4>(c, row, plane);
             int gn;
             if (LSTM) {
                 int unit = n0 + (row & 31);
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
                 gn = gn < N ? gn : N - 1;
             }
             if (BPRE)  // row gn of the image: kt tiles of 192 bytes; chunk c % 12 of the tile
-                bof[i] = (uint32_t)gn * (uint32_t)P.seg[sg].kt3 * 192u + (uint32_t)(c % 12) * 16u;
+                bof[i] = (uint32_t)gn * (uint32_t)P.seg[sg].kt3 * 192u + (uint32_t)(plane * 64 + (c & 3) * 16);
             else
                 bof[i] = ((uint32_t)gn * (uint32_t)P.seg[sg].ldb + (uint32_t)koff) * 4u;
         }
@@ -242,15 +261,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
         MARL_SP_DBGWAIT()                                                                  \
         _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                 \
             const int c_ = tid + 256 * i;                                                  \
-            split_store4(As + (c_ / KC) * SROW + (c_ % KC) * 8, APL, ra_[i].x, ra_[i].y,   \
+            split_store4(As + stage_row(c_) * SROW + (c_ % KC) * 8, APL, ra_[i].x, ra_[i].y, \
                          ra_[i].z, ra_[i].w);                                              \
         }                                                                                  \
         MARL_SP_DBGTS()                                                                    \
         if (BPRE) {                                                                        \
             _Pragma("unroll") for (int i = 0; i < B3_CH; ++i) {                            \
-                const int c_ = tid + 256 * i;                                              \
-                const int rem_ = c_ % 12;                                                  \
-                *reinterpret_cast<u32x4*>(Bs + (rem_ / 4) * BPL + (c_ / 12) * SROW + (rem_ % 4) * 16) = \
+                int row_, pl_;                                                             \
+                image_unit<BN / 4>(tid + 256 * i, row_, pl_);                              \
+                *reinterpret_cast<u32x4*>(Bs + pl_ * BPL + row_ * SROW + (tid & 3) * 16) = \
                     rb3[BPRE ? i : 0];                                                     \
             }                                                                              \
         } else {                                                                           \
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
                     v_.z *= mk_;                                                           \
                     v_.w *= mk_;                                                           \
                 }                                                                          \
-                split_store4(Bs + (c_ / KC) * SROW + (c_ % KC) * 8, BPL, v_.x, v_.y, v_.z, v_.w); \
+                split_store4(Bs + stage_row(c_) * SROW + (c_ % KC) * 8, BPL, v_.x, v_.y, v_.z, v_.w); \
             }                                                                              \
         }                                                                                  \
     }

@@ -1,19 +1,27 @@
-"""profiles/r02_traffic.json from the rocprofv3 --pmc passes (tools/gpu_pmc.sh): HBM bytes per
+"""profiles/<round>_traffic.json from the rocprofv3 --pmc passes (tools/round_profiles.sh): HBM bytes per
 launch of every kernel class of marl_profile_begin, = 2 x FETCH_SIZE (gfx950 correction for wide
-coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KB.
-usage: python tools/make_traffic_json.py TAG"""
+coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KB.  The file is
+stamped with the sha256 of csrc/*.hip|*.h at profiling time; bench.py only quotes it while the
+sources it runs still hash to that value.
+usage: python tools/make_traffic_json.py r03"""
 import csv
 import json
+import os
 import sys
 
-tag = sys.argv[1]
-CLASS_OF = [("gemm_nt_kernel<128, 128, 4, 1, true", 0), ("gemm_nt_kernel", 1), ("gemm_tn_kernel", 2),
-            ("cnn_fwd", 3), ("panel_", 4), ("cnn_dgrad", 5), ("cnn_wgrad", 5)]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import csrc_sha256  # noqa: E402
+
+rnd = sys.argv[1]
+CLASS_OF = [("gemm_nt_kernel<128, 128, 4, 1, true", 0), ("gemm_nt_split_kernel<128, true", 0),
+            ("gemm_nt_kernel", 1), ("gemm_nt_split_kernel", 1), ("gemm_tn_kernel", 2),
+            ("gemm_tn_split_kernel", 2), ("cnn_fwd", 3), ("panel_", 4), ("cnn_dgrad", 5), ("cnn_wgrad", 5),
+            ("cnn_bwd", 5)]
 
 
 def load(c):
     return {r["kernel"]: (int(r["calls"]), float(r[c])) for r in
-            csv.DictReader(open(f"gpurun_out/r02_pmc_{c}_{tag}.csv"))}
+            csv.DictReader(open(f"profiles/{rnd}_bench_c3_pmc_{c.lower()}.csv"))}
 
 
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
@@ -32,8 +40,13 @@ for e in out.values():
     f, w = e.pop("fetch_kb") / n, e.pop("write_kb") / n
     e.update(fetch_size_kb_raw=round(f), write_size_kb=round(w), fetch_correction=2.0,
              traffic_bytes_per_launch=int((2 * f + w) * 1024))
+tot_f = sum(c * f for c, f in F.values())
+tot_w = sum(c * W[k][1] for k, (c, _) in F.items() if k in W)
+out["whole_run_2xfetch_plus_write_gb"] = round((2 * tot_f + tot_w) * 1024 / 1e9, 3)
+out["whole_run_iterations"] = 3
+out["src_sha256"] = csrc_sha256()
 out["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (two separate passes) -- python3 "
-                 f"bench.py --steps 2 --warmup 1 --no-cpu-baseline; per-launch averages per kernel class; summaries in "
-                 f"profiles/r02_bench_c3_pmc_*.csv")
-json.dump(out, open("profiles/r02_traffic.json", "w"), indent=1)
+                 "bench.py --steps 2 --warmup 1 --no-cpu-baseline; per-launch averages per kernel class; summaries in "
+                 f"profiles/{rnd}_bench_c3_pmc_*.csv")
+json.dump(out, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
