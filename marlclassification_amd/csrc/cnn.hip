@@ -411,11 +411,17 @@ __device__ __forceinline__ float cross_row_sum(float v) {
 // full of scalar branches, divisions and kernel-argument reloads and the kernel is bound by
 // instruction issue (measured: 3x slower than this form).  One instantiation per extractor of
 // the reference (networks/vision.py:55-127) at its README window; other shapes use cnn_fwd_kernel.
-template <int F_, int L_, int C0, int C1, int C2, int C3, int G0, int G1, int G2>
+// RP1..RP3 / PP / CP1: LDS padding (floats) of the image rows of layers 1..3, of a patch's region
+// and of layer 1's channel stride.  They only move addresses: chosen (tools/lds_conflicts.py, the
+// bank model of MI355X_MICROARCH.md) so that the 16-lane groups of every ds_read_b128 fragment
+// read - lanes = output positions two image columns / rows apart, quads = adjacent 16-byte
+// pieces - fall on distinct banks.
+template <int F_, int L_, int C0, int C1, int C2, int C3, int C4, int G0, int G1, int G2, int G3,
+          int RP1 = 0, int RP2 = 0, int RP3 = 0, int PP = 0, int CP1 = 4>
 struct Fwd2Net {
     static constexpr int F = F_, L = L_;
-    static constexpr int ch(int l) { return l == 0 ? C0 : l == 1 ? C1 : l == 2 ? C2 : C3; }
-    static constexpr int grp(int l) { return l == 0 ? G0 : l == 1 ? G1 : G2; }
+    static constexpr int ch(int l) { return l == 0 ? C0 : l == 1 ? C1 : l == 2 ? C2 : l == 3 ? C3 : C4; }
+    static constexpr int grp(int l) { return l == 0 ? G0 : l == 1 ? G1 : l == 2 ? G2 : G3; }
     static constexpr int hin(int l) {
         int h = F_;
         for (int i = 0; i < l; ++i) h = (h - 1) / 2 + 1;
@@ -432,10 +438,12 @@ struct Fwd2Net {
     static constexpr int mt(int l) { return (P(l) + 15) / 16; }
     static constexpr int nt(int l) { return (cout(l) + 15) / 16; }
     static constexpr int hp(int l) { return hin(l) + 2; }
-    static constexpr int cs(int l) { return l == 0 ? cin(0) : cin(l) + 4; }
-    static constexpr int in_per(int l) { return (hp(l) * hp(l) * cs(l) + 3) & ~3; }
+    static constexpr int cs(int l) { return l == 0 ? cin(0) : cin(l) + (l == 1 ? CP1 : 4); }
+    static constexpr int rs(int l) { return hp(l) * cs(l) + (l == 1 ? RP1 : l == 2 ? RP2 : l == 3 ? RP3 : 0); }
+    static constexpr int in_per(int l) { return (hp(l) * rs(l) + 3) & ~3; }
     static constexpr int steps(int l) { return (K(l) + 15) / 16; }
-    static constexpr int ldw(int l) { return steps(l) * 16 + 4; }
+    // + 8: the row stride in 16-byte pieces is 2 mod 4 - rows on even pieces, the odd quads beside them
+    static constexpr int ldw(int l) { return steps(l) * 16 + 8; }
     static constexpr int w_floats(int l) { return nt(l) * 16 * ldw(l) + 3 * nt(l) * 16; }
     static constexpr int w_off(int l) {
         int o = 0;
@@ -450,7 +458,7 @@ struct Fwd2Net {
         return m;
     }
     static constexpr int in_off(int l) { return l == 0 ? 0 : in_per(0); }  // deeper images overlay
-    static constexpr int per_patch() { return in_per(0) + amax(); }
+    static constexpr int per_patch() { return in_per(0) + amax() + PP; }
     static constexpr int lds_floats() { return patch_base() + 8 * per_patch(); }
     static constexpr bool ok() {
         for (int l = 0; l < L_; ++l) {
@@ -468,11 +476,11 @@ template <class N, int l>
 __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, float* region, int wave, int lane,
                                            int64_t row0, int nrow) {
     constexpr int P = N::P(l), cin = N::cin(l), cout = N::cout(l), K = N::K(l), hout = N::hout(l), G = N::grp(l);
-    constexpr int cpg = N::cpg(l), hp = N::hp(l), cs = N::cs(l), ldw = N::ldw(l), steps = N::steps(l);
+    constexpr int cpg = N::cpg(l), rs = N::rs(l), cs = N::cs(l), ldw = N::ldw(l), steps = N::steps(l);
     constexpr int MT = N::mt(l), NT = N::nt(l), cp = NT * 16;
     constexpr bool last = l + 1 == N::L;
     constexpr int ln = last ? l : l + 1;
-    constexpr int hp_n = N::hp(ln), cs_n = N::cs(ln), in_per_n = N::in_per(ln);
+    constexpr int rs_n = N::rs(ln), cs_n = N::cs(ln), in_per_n = N::in_per(ln);
     constexpr float inv_cnt = 1.0f / (float)(P * cpg);
     const int quad = lane >> 4, l16 = lane & 15;
     const CnnFwdLayer& Ly = A.layer[l];
@@ -489,7 +497,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
         for (int mt = 0; mt < MT; ++mt) {
             int m = mt * 16 + l16;
             m = m < P ? m : 0;
-            rbase[mt] = (2 * (m / hout) * hp + 2 * (m % hout)) * cs;
+            rbase[mt] = 2 * (m / hout) * rs + 2 * (m % hout) * cs;
         }
         cf32x4 acc[MT][NT];
 #pragma unroll
@@ -504,7 +512,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                 int tap = k0 / cin;
                 const int ci = k0 - tap * cin;
                 tap = tap < 9 ? tap : 8;
-                const int off = ((tap / 3) * hp + tap % 3) * cs + ci;
+                const int off = (tap / 3) * rs + (tap % 3) * cs + ci;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const float4*>(in + rbase[mt] + off);
             } else {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                     int k = k0 + j;
                     k = k < K ? k : K - 1;  // the weight column is zero there
                     const int tap = k / cin, ci = k - tap * cin;
-                    off[j] = ((tap / 3) * hp + tap % 3) * cs + ci;
+                    off[j] = (tap / 3) * rs + (tap % 3) * cs + ci;
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -587,7 +595,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                         if constexpr (last)
                             A.u[prow * (int64_t)A.ldu + ch * P + row] = av;
                         else
-                            nxt[((row / hout + 1) * hp_n + row % hout + 1) * cs_n + ch] = av;
+                            nxt[(row / hout + 1) * rs_n + (row % hout + 1) * cs_n + ch] = av;
                     }
                 }
         }
@@ -599,7 +607,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
             const int gi = task / NT, nt = task - gi * NT;
             const int lr_a = gi * 4 + (l16 >> 2), pos_a = l16 & 3;
             const float* in = lds + N::patch_base() + lr_a * N::per_patch() + N::in_off(l) +
-                              (2 * (pos_a / hout) * hp + 2 * (pos_a % hout)) * cs;
+                              2 * (pos_a / hout) * rs + 2 * (pos_a % hout) * cs;
             const float* wrow = W + (nt * 16 + l16) * ldw + 4 * quad;
             // two accumulators (even / odd 16-deep k steps): the single tile of this wave would
             // otherwise be one dependent chain of matrix instructions
@@ -609,7 +617,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                 int tap = k0 / cin;
                 const int ci = k0 - tap * cin;
                 tap = tap < 9 ? tap : 8;
-                return *reinterpret_cast<const float4*>(in + ((tap / 3) * hp + tap % 3) * cs + ci);
+                return *reinterpret_cast<const float4*>(in + (tap / 3) * rs + (tap % 3) * cs + ci);
             };
             float4 a0 = fragA(0), b0 = *reinterpret_cast<const float4*>(wrow);
             float4 a1 = fragA(1 < steps ? 1 : 0), b1 = *reinterpret_cast<const float4*>(wrow + (1 < steps ? 16 : 0));
@@ -765,14 +773,14 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
         const int nrow = (int)(A.rows - row0 < 8 ? A.rows - row0 : 8);
         // ---- raw patch -> this wave's zero-bordered input image (HWC)
         {
-            constexpr int hp = N::hp(0), cs = N::cs(0);
+            constexpr int rs = N::rs(0), cs = N::cs(0);
             float* in0 = region + N::in_off(0);
 #pragma unroll
             for (int i = 0; i < kPF; ++i) {
                 const int e = lane + 64 * i;
                 if (e < pe) {
                     const int ci = e / ff, e2 = e - ci * ff, iy = e2 / f, ix = e2 - iy * f;
-                    in0[((iy + 1) * hp + ix + 1) * cs + ci] = pf[i];
+                    in0[(iy + 1) * rs + (ix + 1) * cs + ci] = pf[i];
                 }
             }
         }
@@ -789,9 +797,9 @@ __global__ __launch_bounds__(512) void cnn_fwd2_kernel(const CnnFwdArgs A, const
 }
 
 // the extractor shapes cnn_fwd2_kernel is built for
-using Fwd2Resisc = Fwd2Net<12, 3, 3, 16, 32, 64, 2, 4, 8>;   // Resisc45Cnn / SkinCancerCnn, f = 12
-using Fwd2Mnist6 = Fwd2Net<6, 2, 1, 8, 16, 0, 2, 4, 1>;      // MnistCnn, f = 6 (README)
-using Fwd2Mnist12 = Fwd2Net<12, 2, 1, 8, 16, 0, 2, 4, 1>;    // MnistCnn, f = 12 (the reference's tests)
+using Fwd2Resisc = Fwd2Net<12, 3, 3, 16, 32, 64, 0, 2, 4, 8, 0, 4, 28, 0, 4>;  // Resisc45Cnn / SkinCancerCnn, f = 12
+using Fwd2Mnist6 = Fwd2Net<6, 2, 1, 8, 16, 0, 0, 2, 4, 1, 0>;           // MnistCnn, f = 6 (README)
+using Fwd2Mnist12 = Fwd2Net<12, 2, 1, 8, 16, 0, 0, 2, 4, 1, 0, 28>;     // MnistCnn, f = 12 (the reference's tests)
 static_assert(Fwd2Resisc::ok() && Fwd2Mnist6::ok() && Fwd2Mnist12::ok(), "fwd2 nets");
 
 template <class N>
