@@ -458,6 +458,7 @@ struct Fwd2Net {
         return m;
     }
     static constexpr int in_off(int l) { return l == 0 ? 0 : in_per(0); }  // deeper images overlay
+    static constexpr int ppad() { return PP; }
     static constexpr int per_patch() { return in_per(0) + amax() + PP; }
     static constexpr int lds_floats() { return patch_base() + 8 * per_patch(); }
     static constexpr bool ok() {
@@ -470,6 +471,11 @@ struct Fwd2Net {
         return cin(0) * F_ * F_ <= 512 && lds_floats() * 4 <= 160 * 1024;
     }
 };
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter,
+// i.e. every prefetch (next group's pixels, next layer's weight fragments) would be waited for at the
+// next barrier (measured: 8.8 us per group).  Global stores need no ordering inside this kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // one layer of cnn_fwd2_kernel for this wave (mode 0) or this workgroup (mode 1)
 template <class N, int l>
@@ -601,7 +607,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
         }
     } else {
         // ================= 16-row tiles over 4 patches (P == 4), one (row tile, column tile) per turn
-        __syncthreads();  // the other waves' images of this layer's input are complete
+        lds_barrier();  // the other waves' images of this layer's input are complete
         constexpr int ntask = 2 * NT;  // 8 patches * 4 positions = 2 row tiles
         for (int task = wave; task < ntask; task += 8) {
             const int gi = task / NT, nt = task - gi * NT;
@@ -677,7 +683,7 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                 }
             }
         }
-        __syncthreads();  // before the next chunk's layers overwrite the images read above
+        lds_barrier();  // before the next chunk's layers overwrite the images read above
     }
 }
 
@@ -841,12 +847,540 @@ static int fwd2_launch(CnnFwdArgs& a, hipStream_t st) {
     return MARL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// cnn_fwd3_kernel: the same fused extractor for the DEEP shapes (AidCnn: four layers, window 24 /
+// 32, 128 output channels; networks/vision.py:73-77).  A wave cannot own such a patch - its
+// images alone are 25-40 KB and the last two layers' weights 370 KB - so here a WORKGROUP owns
+// GP = 4 patches and every layer is cut into tasks (patch block x 16-channel tile) for its eight
+// waves:
+//   * a task holds all positions of its patches, so the GroupNorm statistics still come from the
+//     accumulator registers (cross-lane sums), never through memory;
+//   * layers >= 1 read their weight fragments straight from global memory (L2-resident), a block
+//     of K steps ahead in registers; a task covers PB patches so that a fragment is used
+//     PB x MT times; only layer 0's weights (2.5 KB) sit in LDS;
+//   * the last layer (4 positions per patch) packs the 4 patches into one 16-row tile per
+//     channel tile, as cnn_fwd2 does;
+//   * images ping-pong between two LDS regions per patch; the next image's zero border is
+//     written by all threads while the tasks' K loops run (barrier before the epilogues).
+// Tasks per layer are 4 or 8: one per SIMD or two - the matrix pipe, which bounds this kernel
+// (v_mfma_f32_16x16x4f32: 32 cycles per 2 KFLOP), stays evenly loaded.
+// ---------------------------------------------------------------------------
+template <class N, int GP_>
+struct Fwd3Plan {
+    static constexpr int GP = GP_, NWV = 8;
+    // measured on C4 / C5: two patches per task at most (eight tasks keep two waves per SIMD busy: 45.7 vs
+    // 49.7 us at C4) and ONE early weight block (two: the fragments held across the epilogue spill, 55 us)
+    static constexpr int EARLY_BLOCKS = 1, PB_CAP = 2;
+    static constexpr int max2(int a, int b) { return a > b ? a : b; }
+    static constexpr int even_max() {
+        int m = 0;
+        for (int l = 0; l < N::L; l += 2) m = max2(m, N::in_per(l));
+        return m;
+    }
+    static constexpr int odd_max() {
+        int m = 0;
+        for (int l = 1; l < N::L; l += 2) m = max2(m, N::in_per(l));
+        return m;
+    }
+    static constexpr int reg_off(int l) { return (l & 1) ? even_max() : 0; }
+    static constexpr int per_patch() { return even_max() + odd_max() + N::ppad(); }
+    static constexpr int img_base() { return N::w_floats(0); }
+    static constexpr int lds_floats() { return img_base() + GP * per_patch(); }
+    // patches per task: <= 8 accumulator tiles, a power of two, <= PB_CAP
+    static constexpr int pb(int l) {
+        if (N::mode(l) == 1) return GP;
+        int b = 8 / N::mt(l);
+        b = b >= 4 ? 4 : b >= 2 ? 2 : 1;
+        b = b < PB_CAP ? b : PB_CAP;
+        return b < GP ? b : GP;
+    }
+    static constexpr int ntask(int l) { return N::mode(l) == 1 ? N::nt(l) : (GP / pb(l)) * N::nt(l); }
+    // K steps per weight-fragment block (registers: 4 per step): the largest divisor of steps <= 12
+    static constexpr int kb(int l) {
+        if (l <= 0 || l >= N::L) return 1;
+        int b = 1;
+        for (int d = 1; d <= 12; ++d)
+            if (N::steps(l) % d == 0) b = d;
+        return b;
+    }
+    static constexpr int nblk(int l) { return N::steps(l) / kb(l); }
+    // K steps of layer l whose weight fragments the PREVIOUS layer requests (two blocks at most)
+    static constexpr int early(int l) {
+        if (l <= 0 || l >= N::L) return 1;
+        return (nblk(l) < EARLY_BLOCKS ? nblk(l) : EARLY_BLOCKS) * kb(l);
+    }
+    static constexpr int bsteps(int l) { return (l <= 0 || l >= N::L) ? 1 : N::steps(l); }
+    static constexpr bool ok() {
+        if (N::L != 4 || N::mode(N::L - 1) != 1 || GP != 4) return false;
+        for (int l = 0; l < N::L; ++l) {
+            const int c = N::cpg(l);
+            if (N::cout(l) % N::grp(l) != 0 || (c & (c - 1)) || c > 16 || (N::cout(l) & 15)) return false;
+            if (l > 0 && (N::cin(l) & 15)) return false;  // a 16-deep K step stays inside one tap
+            if (ntask(l) > NWV || N::mt(l) > 16) return false;
+        }
+        return lds_floats() * 4 <= 160 * 1024;
+    }
+};
+
+#ifdef MARL_KERNEL_TS
+#define MARL_F3_TS() if (ts_ && (threadIdx.x & 63) == 0 && blockIdx.x == 37 && tsi_ < 48) ts_[(threadIdx.x >> 6) * 48 + tsi_++] = wall_clock64()
+#define MARL_F3_TSARGS , long long* ts_, int& tsi_
+#define MARL_F3_TSPASS , ts_, tsi_
+#else
+#define MARL_F3_TS()
+#define MARL_F3_TSARGS
+#define MARL_F3_TSPASS
+#endif
+
+// this wave's weight-fragment pointer in layer l (global memory, fragment order - CnnFwdLayer::wfrag: a K
+// step of a 16-channel tile is 1 KB contiguous, one float4 per lane; from the row-major copy a wave's load
+// touched 16 rows x 64 B, half of every cache line): null when the wave has no task there
+template <class N, class PL, int l>
+__device__ __forceinline__ const float* fwd3_wrow(const CnnFwdArgs& A, int wave, int lane) {
+    if constexpr (l <= 0 || l >= N::L) {
+        return nullptr;
+    } else {
+        if (wave >= PL::ntask(l)) return nullptr;
+        const int nt = N::mode(l) == 1 ? wave : wave % N::nt(l);
+        return A.layer[l].wfrag + ((size_t)nt * N::steps(l) * 64 + lane) * 4;  // + 256 floats per K step
+    }
+}
+// K steps [lo, hi) of a task's weight fragments -> registers
+template <int LO, int HI, int NB>
+__device__ __forceinline__ void fwd3_loadb(float4 (&b)[NB], const float* wrow) {
+#pragma unroll
+    for (int j = LO; j < HI; ++j) b[j] = *reinterpret_cast<const float4*>(wrow + j * 256);
+}
+
+// bw: this layer's weight fragments, one float4 per K step - the first PL::early(l) steps were requested
+// by the previous layer, the rest is requested at the head of the K loop; bwn: the next layer's, whose
+// early steps are requested here between the K loop and the epilogue (in flight across the epilogue
+// and two barriers).  (hipcc moves a one-block-ahead prefetch written as a rotating pair of register
+// sets down to its first use; every block therefore has its own registers.)
+template <class N, class PL, int l, int KB0, int KBN>
+__device__ __forceinline__ void fwd3_layer(const CnnFwdArgs& A, float* lds, int tid, int64_t row0, int nrow,
+                                           float4 (&bw)[KB0], float4 (&bwn)[KBN] MARL_F3_TSARGS) {
+    constexpr int P = N::P(l), cin = N::cin(l), cout = N::cout(l), K = N::K(l), hout = N::hout(l), G = N::grp(l);
+    constexpr int cpg = N::cpg(l), rs = N::rs(l), cs = N::cs(l), steps = N::steps(l);
+    constexpr int MT = N::mt(l), NT = N::nt(l), PB = PL::pb(l), NTASK = PL::ntask(l);
+    constexpr int KB = PL::kb(l), NBLK = PL::nblk(l);
+    static_assert(l == 0 || KB0 == steps, "one fragment per K step");
+    (void)NBLK;
+    constexpr bool last = l + 1 == N::L;
+    constexpr int ln = last ? 0 : l + 1;  // the region zeroed during this layer: next image / next group's input
+    constexpr int rs_n = N::rs(ln), cs_n = N::cs(ln);
+    constexpr float inv_cnt = 1.0f / (float)(P * cpg);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = lane >> 4, l16 = lane & 15;
+    const CnnFwdLayer& Ly = A.layer[l];
+    float* const img = lds + PL::img_base();
+    const bool has_task = wave < NTASK;
+    const float* const wrow = fwd3_wrow<N, PL, l>(A, wave, lane);
+    const float* const wrow_n = fwd3_wrow<N, PL, l + 1>(A, wave, lane);
+
+    // ---- every thread: zero border (whole image) of the region this layer's epilogues write into
+    {
+        constexpr int n4 = N::in_per(ln) >> 2;
+        for (int i = tid; i < PL::GP * n4; i += 512) {
+            const int p = i / n4, r = i - p * n4;
+            *reinterpret_cast<float4*>(img + p * PL::per_patch() + PL::reg_off(ln) + 4 * r) =
+                make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if constexpr (N::mode(l) == 0) {
+        const int nt = has_task ? wave % NT : 0, pg = has_task ? wave / NT : 0;
+        const int ch = nt * 16 + l16;
+        constexpr int KA = (MT == 1 && l > 0) ? 2 : 1;  // a single tile: even / odd K steps in two chains
+        cf32x4 acc[KA][PB][MT];
+        if (has_task) {
+#pragma unroll
+            for (int a = 0; a < KA; ++a)
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[a][p][mt] = cf32x4{0.f, 0.f, 0.f, 0.f};
+            int rbase[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int m = mt * 16 + l16;
+                m = m < P ? m : 0;
+                rbase[mt] = 2 * (m / hout) * rs + 2 * (m % hout) * cs;
+            }
+            const float* in0 = img + (pg * PB) * PL::per_patch() + PL::reg_off(l);
+            if constexpr (l == 0) {
+                // K = 9 * cin (27): scalar taps, weights in LDS
+                const float* W = lds + (nt * 16 + l16) * N::ldw(0);
+#pragma unroll
+                for (int kk = 0; kk < steps; ++kk) {
+                    const int k0 = kk * 16 + 4 * quad;
+                    int off[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int k = k0 + j;
+                        k = k < K ? k : K - 1;  // the weight column is zero there
+                        const int tap = k / cin, ci = k - tap * cin;
+                        off[j] = (tap / 3) * rs + (tap % 3) * cs + ci;
+                    }
+                    const float4 b = *reinterpret_cast<const float4*>(W + k0);
+                    constexpr int MB = MT < 4 ? MT : 4;
+#pragma unroll
+                    for (int p = 0; p < PB; ++p)
+#pragma unroll
+                        for (int m0 = 0; m0 < MT; m0 += MB) {
+                            float4 a[MB];
+#pragma unroll
+                            for (int i = 0; i < MB; ++i) {
+                                const float* q = in0 + p * PL::per_patch() + rbase[m0 + i < MT ? m0 + i : MT - 1];
+                                a[i] = make_float4(q[off[0]], q[off[1]], q[off[2]], q[off[3]]);
+                            }
+#define MARL_F3_MFMA(q_)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MB; ++i) if (m0 + i < MT)                           \
+        acc[0][p][m0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].q_, b.q_, acc[0][p][m0 + i], 0, 0, 0);
+                            MARL_F3_MFMA(x) MARL_F3_MFMA(y) MARL_F3_MFMA(z) MARL_F3_MFMA(w)
+#undef MARL_F3_MFMA
+                        }
+                }
+            } else {
+                fwd3_loadb<PL::early(l), steps>(bw, wrow);
+                {
+#pragma unroll
+                    for (int kk = 0; kk < steps; ++kk) {
+                        const int k0 = kk * 16;
+                        const int tap = k0 / cin, ci = k0 - tap * cin;
+                        const int off = (tap / 3) * rs + (tap % 3) * cs + ci + 4 * quad;
+#pragma unroll
+                        for (int p = 0; p < PB; ++p) {
+                            float4 a[MT];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                a[mt] = *reinterpret_cast<const float4*>(in0 + p * PL::per_patch() + rbase[mt] + off);
+#define MARL_F3_MFMA(q_)                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                         \
+        acc[KA == 2 ? (kk & 1) : 0][p][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(            \
+            a[mt].q_, bw[kk].q_, acc[KA == 2 ? (kk & 1) : 0][p][mt], 0, 0, 0);
+                            MARL_F3_MFMA(x) MARL_F3_MFMA(y) MARL_F3_MFMA(z) MARL_F3_MFMA(w)
+#undef MARL_F3_MFMA
+                        }
+                    }
+                }
+                if constexpr (KA == 2)
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) acc[0][p][0] += acc[KA - 1][p][0];
+            }
+        }
+        if (wrow_n) fwd3_loadb<0, PL::early(l + 1)>(bwn, wrow_n);
+        // (the per-channel vectors are requested ahead of the barrier too)
+        const float bv = l == 0 ? lds[N::p_off(0) + ch] : Ly.bias[ch];
+        const float gm = l == 0 ? lds[N::p_off(0) + NT * 16 + ch] : Ly.gamma[ch];
+        const float bt = l == 0 ? lds[N::p_off(0) + 2 * NT * 16 + ch] : Ly.beta[ch];
+        MARL_F3_TS();
+        lds_barrier();  // the zero borders are complete before any epilogue writes an interior
+        MARL_F3_TS();
+        if (has_task) {
+            // ---- bias, GroupNorm statistics from the registers (two passes), SiLU  (as cnn_fwd2)
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int lp = pg * PB + p;
+                const int64_t prow = row0 + lp;
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][p][mt][r] += bv;
+                        if (mt * 16 + 4 * quad + r < P) s += acc[0][p][mt][r];
+                    }
+                s = row_block_sum(cross_row_sum(s), cpg);
+                const float mean = s * inv_cnt;
+                float q = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mt * 16 + 4 * quad + r < P) {
+                            const float d = acc[0][p][mt][r] - mean;
+                            q += d * d;
+                        }
+                q = row_block_sum(cross_row_sum(q), cpg);
+                const float rstd = 1.0f / sqrtf(q * inv_cnt + 1e-5f);
+                const bool mine = lp < nrow;
+                if (mine && Ly.gst && quad == 0 && (l16 & (cpg - 1)) == 0) {
+                    float* gs = Ly.gst + (prow * G + ch / cpg) * 2;
+                    gs[0] = mean;
+                    gs[1] = rstd;
+                }
+                float* nxt = img + lp * PL::per_patch() + PL::reg_off(ln);
+                float* zp = Ly.z ? Ly.z + prow * (int64_t)(P * cout) + ch : nullptr;  // + row * cout
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = mt * 16 + 4 * quad + r;
+                        if (row < P) {
+                            const float zv = acc[0][p][mt][r];
+                            if (mine && zp) zp[row * cout] = zv;
+                            const float av = cnn_silu((zv - mean) * rstd * gm + bt);
+                            if constexpr (last) {
+                                if (mine) A.u[prow * (int64_t)A.ldu + ch * P + row] = av;
+                            } else {
+                                nxt[(row / hout + 1) * rs_n + (row % hout + 1) * cs_n + ch] = av;
+                            }
+                        }
+                    }
+            }
+        }
+        MARL_F3_TS();
+        lds_barrier();  // next layer reads the images
+        MARL_F3_TS();
+    } else {
+        // ================= last layer, P == 4: one 16-row tile = the 4 patches x 4 positions
+        static_assert(PL::GP == 4 && last, "packed last layer");
+        if (has_task) {
+            const int nt = wave;
+            const int ch = nt * 16 + l16;
+            const float bv = Ly.bias[ch], gm = Ly.gamma[ch], bt = Ly.beta[ch];
+            const int lr_a = l16 >> 2, pos_a = l16 & 3;
+            const float* in = img + lr_a * PL::per_patch() + PL::reg_off(l) +
+                              2 * (pos_a / hout) * rs + 2 * (pos_a % hout) * cs + 4 * quad;
+            cf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            fwd3_loadb<PL::early(l), steps>(bw, wrow);
+            constexpr int AB = 4;  // image fragments read per batch
+            static_assert(steps % AB == 0, "K steps per batch");
+#pragma unroll
+            for (int kb = 0; kb < steps; kb += AB) {
+                float4 a[AB];
+#pragma unroll
+                for (int j = 0; j < AB; ++j) {
+                    const int k0 = (kb + j) * 16;
+                    const int tap = k0 / cin, ci = k0 - tap * cin;
+                    a[j] = *reinterpret_cast<const float4*>(in + (tap / 3) * rs + (tap % 3) * cs + ci);
+                }
+#define MARL_F3_MFMA(q_)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < AB; ++j) {                                          \
+        if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].q_, bw[kb + j].q_, acc1, 0, 0, 0); \
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].q_, bw[kb + j].q_, acc0, 0, 0, 0); \
+    }
+                MARL_F3_MFMA(x) MARL_F3_MFMA(y) MARL_F3_MFMA(z) MARL_F3_MFMA(w)
+#undef MARL_F3_MFMA
+            }
+            acc0 += acc1;
+            // lane (quad, l16) holds patch quad, positions r = 0..3, channel nt * 16 + l16
+            const bool pv = quad < nrow;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0[r] += bv;
+                s += acc0[r];
+            }
+            s = row_block_sum(s, cpg);
+            const float mean = s * inv_cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc0[r] - mean;
+                q += d * d;
+            }
+            q = row_block_sum(q, cpg);
+            const float rstd = 1.0f / sqrtf(q * inv_cnt + 1e-5f);
+            const int64_t orow = row0 + quad;
+            if (pv) {
+                if (Ly.gst && (l16 & (cpg - 1)) == 0) {
+                    float* gs = Ly.gst + (orow * G + ch / cpg) * 2;
+                    gs[0] = mean;
+                    gs[1] = rstd;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float zv = acc0[r];
+                    if (Ly.z) Ly.z[(orow * P + r) * (int64_t)cout + ch] = zv;
+                    A.u[orow * (int64_t)A.ldu + ch * P + r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                }
+            }
+        }
+        MARL_F3_TS();
+        lds_barrier();  // region 0 is zeroed and free: the next group's pixels may land
+        MARL_F3_TS();
+    }
+}
+
+template <class N, class PL>
+__global__ __launch_bounds__(512) void cnn_fwd3_kernel(const CnnFwdArgs A, const int ngroups) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    constexpr int GP = PL::GP, f = N::F, ff = f * f, pe = N::cin(0) * ff;
+    constexpr int kPF = (GP * pe + 511) / 512;  // gathered pixels per thread and group
+    const float* imgf = static_cast<const float*>(A.img);
+    const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+    float pf[kPF];
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(A.ts);
+#endif
+    MARL_F3_TS();
+    // Pixels of the GP patches of group `grp`.  Every load is UNCONDITIONAL with clamped indices (a load
+    // behind a branch makes hipcc wait for each one in turn - measured: 12 us for the first group's 24
+    // loads per lane); rows past the end re-read the last patch, their results are never stored.
+    auto prefetch = [&](int grp) {
+        const int64_t r0 = (int64_t)(grp < ngroups ? grp : ngroups - 1) * GP;
+        int py[GP], px[GP], rr[GP], ib[GP];  // position, patch row, image of the patch (one division per patch)
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+            const int64_t r = r0 + p < A.rows ? r0 + p : A.rows - 1;
+            rr[p] = (int)r;
+            ib[p] = (int)((uint32_t)r % (uint32_t)A.nb);
+            py[p] = A.obs ? 0 : A.pos[r * 2];
+            px[p] = A.obs ? 0 : A.pos[r * 2 + 1];
+        }
+#define MARL_F3_INDEX(i_)                                                                     \
+    int e = tid + 512 * (i_);                                                                 \
+    asm volatile("" : "+v"(e)); /* recomputed per group: the index chains are not kept in registers */ \
+    e = e < GP * pe ? e : GP * pe - 1;                                                        \
+    const int p = e / pe, e1 = e - p * pe;                                                    \
+    int y0 = py[0], x0 = px[0], r = rr[0], b = ib[0];                                         \
+    _Pragma("unroll") for (int q = 1; q < GP; ++q) if (p == q) {                              \
+        y0 = py[q];                                                                           \
+        x0 = px[q];                                                                           \
+        r = rr[q];                                                                            \
+        b = ib[q];                                                                            \
+    }                                                                                         \
+    const int ci = e1 / ff, e2 = e1 - ci * ff, iy = e2 / f, ix = e2 - iy * f;                 \
+    const int64_t oi = (int64_t)(b * A.c_img + ci) * ((int64_t)A.H * A.W) + ((y0 + iy) * A.W + (x0 + ix)); \
+    const int64_t oo = (int64_t)r * (A.c_img * ff) + e1;                                      \
+    (void)oi;                                                                                 \
+    (void)oo;
+        if (A.obs) {
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                MARL_F3_INDEX(i)
+                pf[i] = A.obs[oo];
+            }
+        } else if (A.img_u8) {
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                MARL_F3_INDEX(i)
+                pf[i] = (float)imgb[oi];  // (/ 255 when the pixel goes to LDS: ToTensor on the fly)
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                MARL_F3_INDEX(i)
+                pf[i] = imgf[oi];
+            }
+        }
+#undef MARL_F3_INDEX
+    };
+    prefetch(blockIdx.x);  // in flight while LDS is set up
+    // ---- one-time: zero layer 0's weight area and the patches' first region (borders), then layer 0's
+    // weights and per-channel vectors -> LDS
+    for (int i = tid; i < (PL::img_base() >> 2); i += 512)
+        *reinterpret_cast<float4*>(lds + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        constexpr int n4 = N::in_per(0) >> 2;
+        for (int i = tid; i < GP * n4; i += 512) {
+            const int p = i / n4, r = i - p * n4;
+            *reinterpret_cast<float4*>(lds + PL::img_base() + p * PL::per_patch() + 4 * r) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    lds_barrier();
+    {
+        const CnnFwdLayer& Ly = A.layer[0];
+        constexpr int k4 = N::ldk(0) >> 2, cout = N::cout(0), cp = N::nt(0) * 16;
+        for (int idx = tid; idx < cout * k4; idx += 512) {
+            const int n = idx / k4, c = (idx - n * k4) * 4;
+            *reinterpret_cast<float4*>(lds + n * N::ldw(0) + c) = *reinterpret_cast<const float4*>(Ly.w + 4 * idx);
+        }
+        float* pv = lds + N::p_off(0);
+        for (int c = tid; c < cout; c += 512) {
+            pv[c] = Ly.bias[c];
+            pv[cp + c] = Ly.gamma[c];
+            pv[2 * cp + c] = Ly.beta[c];
+        }
+    }
+    MARL_F3_TS();
+
+    float4 bw1[PL::bsteps(1)], bw2[PL::bsteps(2)], bw3[PL::bsteps(3)], bnone[1];
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t row0 = (int64_t)grp * GP;
+        const int nrow = (int)(A.rows - row0 < GP ? A.rows - row0 : GP);
+        // ---- raw patches -> zero-bordered input images (HWC) in region 0
+        {
+            constexpr int rs = N::rs(0), cs = N::cs(0);
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                int e = tid + 512 * i;
+                asm volatile("" : "+v"(e));
+                const int p = e / pe, e1 = e - p * pe;
+                if (p < GP) {
+                    const int ci = e1 / ff, e2 = e1 - ci * ff, iy = e2 / f, ix = e2 - iy * f;
+                    lds[PL::img_base() + p * PL::per_patch() + (iy + 1) * rs + (ix + 1) * cs + ci] =
+                        (A.img_u8 && !A.obs) ? pf[i] / 255.0f : pf[i];
+                }
+            }
+        }
+        MARL_F3_TS();
+        prefetch(grp + gridDim.x);  // the next group's pixels fly during this group's layers
+        lds_barrier();
+        MARL_F3_TS();
+        // an opaque copy of the thread index per layer: everything derived from it (tile bases, zeroing
+        // addresses, weight pointers of FOUR layers) would otherwise be hoisted out of the group loop
+        // and spilled (measured: 146 scratch stores ahead of the loop, 75 reloads in one epilogue)
+        int t0 = tid, t1 = tid, t2 = tid, t3 = tid;
+        asm volatile("" : "+v"(t0));
+        fwd3_layer<N, PL, 0>(A, lds, t0, row0, nrow, bnone, bw1 MARL_F3_TSPASS);
+        asm volatile("" : "+v"(t1));
+        fwd3_layer<N, PL, 1>(A, lds, t1, row0, nrow, bw1, bw2 MARL_F3_TSPASS);
+        asm volatile("" : "+v"(t2));
+        fwd3_layer<N, PL, 2>(A, lds, t2, row0, nrow, bw2, bw3 MARL_F3_TSPASS);
+        asm volatile("" : "+v"(t3));
+        fwd3_layer<N, PL, 3>(A, lds, t3, row0, nrow, bw3, bnone MARL_F3_TSPASS);
+    }
+}
+
+using Fwd3Aid24 = Fwd2Net<24, 4, 3, 16, 32, 64, 128, 2, 4, 8, 16, 0, 20, 28, 0, 4>;  // AidCnn, f = 24 (configs[3])
+using Fwd3Aid32 = Fwd2Net<32, 4, 3, 16, 32, 64, 128, 2, 4, 8, 16, 4, 8, 24, 8, 0>;   // AidCnn, f = 32 (configs[4])
+using Plan3Aid24 = Fwd3Plan<Fwd3Aid24, 4>;
+using Plan3Aid32 = Fwd3Plan<Fwd3Aid32, 4>;
+static_assert(Plan3Aid24::ok() && Plan3Aid32::ok(), "fwd3 nets");
+
+template <class N, class PL>
+static int fwd3_launch(CnnFwdArgs& a, hipStream_t st) {
+    static bool raised = false;  // per process; one process drives one GPU
+    auto kern = cnn_fwd3_kernel<N, PL>;
+    constexpr size_t lds = (size_t)PL::lds_floats() * sizeof(float);
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const int ngroups = (int)cdiv(a.rows, PL::GP);
+    const int blocks = ngroups < 256 ? ngroups : 256;
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts3 = nullptr;
+    static int calls3 = 0;
+    const int rec3 = ts_begin(&d_ts3, calls3++);
+    a.ts = rec3 ? d_ts3 : nullptr;
+#endif
+    prof_before(3, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, ngroups);
+    prof_after(3, st);
+    MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec3) ts_report("cnn_fwd3", d_ts3, 8);
+#endif
+    return MARL_OK;
+}
+
 // 0 = not covered, else 1 + index of the instantiation
 static int cnn_fwd2_which(const CnnFwdArgs& a) {
     if (!tune_get("cnn_fwd2", 1)) return 0;
     if (fwd2_matches<Fwd2Resisc>(a)) return 1;
     if (fwd2_matches<Fwd2Mnist6>(a)) return 2;
     if (fwd2_matches<Fwd2Mnist12>(a)) return 3;
+    if (tune_get("cnn_fwd3", 1)) {
+        for (int l = 1; l < a.L; ++l)
+            if (!a.layer[l].wfrag) return 0;  // (no weights workspace behind this call)
+        if (fwd2_matches<Fwd3Aid24>(a)) return 4;
+        if (fwd2_matches<Fwd3Aid32>(a)) return 5;
+    }
     return 0;
 }
 
@@ -902,6 +1436,8 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
         case 1: return fwd2_launch<Fwd2Resisc>(a, st);
         case 2: return fwd2_launch<Fwd2Mnist6>(a, st);
         case 3: return fwd2_launch<Fwd2Mnist12>(a, st);
+        case 4: return fwd3_launch<Fwd3Aid24, Plan3Aid24>(a, st);
+        case 5: return fwd3_launch<Fwd3Aid32, Plan3Aid32>(a, st);
         default: break;
     }
     // as many patches per workgroup as fit three workgroups per CU (the conv weights are

@@ -535,6 +535,9 @@ struct CnnFwdLayer {
     float* z;                              // [R * P][cout] conv output kept for backward (or null)
     float* gst;                            // [R][G][2] mean / rstd (or null)
     int cin, cout, G, hin, hout, P, K, ldk;
+    // optional: the weight in MFMA-fragment order (cnn_fwd3): [cout / 16][K / 16][64 lanes][4], lane
+    // (quad, l16) = row 16 nt + l16, k = 16 kk + 4 quad .. + 3 - one K step of a tile is 1 KB contiguous
+    const float* wfrag;
 };
 struct CnnFwdArgs {
     const void* img;     // [Nb][c_img][H][W] float or uint8

@@ -195,15 +195,19 @@ struct WLayout {
     int ldt[MARL_NPARAMS];
     size_t gp[MARL_NPARAMS];  // packed gradient (same shape as wp)
     size_t wp3[MARL_NPARAMS], wt3[MARL_NPARAMS];  // bf16x3 images of wp / wt (gemm_split.hip)
+    size_t wf[MARL_NPARAMS];  // conv weights in MFMA-fragment order (cnn_fwd3), 0 = none
     size_t bsum_b, bsum_a;    // b_ih + b_hh
     size_t total;
 };
+
+// conv weights whose tiles are whole (16 output channels x 16-deep K steps) get a fragment-order copy
+static bool conv_frag_ok(const ParamMeta& m) { return m.kind == PK_CONV && m.n % 16 == 0 && m.k % 16 == 0; }
 
 static void make_wlayout(const Dims& d, WLayout& w) {
     Bump b;
     for (int i = 0; i < MARL_NPARAMS; ++i) {
         const ParamMeta m = param_meta(d, i);
-        w.wp[i] = w.wt[i] = w.gp[i] = w.wp3[i] = w.wt3[i] = 0;
+        w.wp[i] = w.wt[i] = w.gp[i] = w.wp3[i] = w.wt3[i] = w.wf[i] = 0;
         w.ldp[i] = w.ldt[i] = 0;
         if (m.kind == PK_MATRIX || m.kind == PK_CONV) {
             w.ldp[i] = p4(m.k);
@@ -214,6 +218,9 @@ static void make_wlayout(const Dims& d, WLayout& w) {
             if (m.kind == PK_MATRIX) {
                 w.wp3[i] = b.take(split_image_floats(m.n, m.k));
                 w.wt3[i] = b.take(split_image_floats(m.k, m.n));
+            } else if (conv_frag_ok(m)) {
+                b.take(16);  // (offset 0 means "none")
+                w.wf[i] = b.take((size_t)m.n * m.k);
             }
         } else if (m.kind == PK_VEC) {
             w.ldp[i] = m.n;
@@ -269,7 +276,7 @@ static CnnFwdArgs cnn_fwd_shape(const Dims& d) {
     for (int l = 0; l < d.L; ++l)
         a.layer[l] = CnnFwdLayer{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                  d.ch[l], d.ch[l + 1], d.grp[l], d.hw[l], d.hw[l + 1], d.P[l], d.K[l],
-                                 d.ldk[l]};
+                                 d.ldk[l], nullptr};
     return a;
 }
 static CnnWgradArgs cnn_wgrad_shape(const Dims& d, int l) {
@@ -581,7 +588,7 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
                                      keep ? c.at(c.e.Z[l], t) : nullptr,
                                      keep ? c.at(c.e.GST[l], t) : nullptr,
                                      d.ch[l], d.ch[l + 1], d.grp[l], d.hw[l], d.hw[l + 1], d.P[l],
-                                     d.K[l], d.ldk[l]};
+                                     d.K[l], d.ldk[l], c.w.wf[4 * l] ? c.W + c.w.wf[4 * l] : nullptr};
         a.u = c.at(c.e.U, t);
         a.ldu = d.ld_nin;
         if (c.e.fused_fwd) return launch_cnn_fwd(a, st);
@@ -987,6 +994,17 @@ static int pack_weights(const Dims& d, const WLayout& w, const float* const* par
                 params[MARL_P_LB_BHH]));
     q.push(perm(params[MARL_P_LA_BIH], W + w.bsum_a, 1, 4 * d.n_a, 4 * d.n_a, 1, 0, 0, 1, 1, 0,
                 params[MARL_P_LA_BHH]));
+    q.flush();
+    MARL_TRY(q.rc);
+    // fragment-order copies of the deeper conv weights (read back from the packed copies just written):
+    // dst row (nt * steps + kk) * 4 + quad, column l16 * 4 + j  <-  packed [nt * 16 + l16][kk * 16 + quad * 4 + j]
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        if (!w.wf[i]) continue;
+        const int steps = m.k / 16;
+        q.push(perm(W + w.wp[i], W + w.wf[i], (m.n / 16) * steps * 4, 64, 64, steps * 4, 16 * w.ldp[i], 4, 4,
+                    w.ldp[i], 1));
+    }
     q.flush();
     MARL_TRY(q.rc);
     // bf16x3 images of every matrix copy (read back from the fp32 copies just written)

@@ -2,6 +2,7 @@
 wave-instruction = sum over its lane groups of the most-loaded bank's distinct addresses.
   python tools/lds_conflicts.py gemm     staging stores / fragment reads of the bf16x6 kernels
   python tools/lds_conflicts.py cnn      searches the row / patch pads of the cnn_fwd2 images
+  python tools/lds_conflicts.py cnn3     the same for the cnn_fwd3 (AidCnn) images
 The pads found here are the RP1.. / PP template arguments of Fwd2Net (csrc/cnn.hip)."""
 import sys
 
@@ -158,5 +159,41 @@ def cnn():
     search("Mnist f=12", 12, [1, 8, 16], False)
 
 
+
+
+def search3(name, f, chs, cp1s=(0, 4)):
+    """cnn_fwd3 (workgroup-owned patch groups): layers 1..L-2 independently, then the packed last layer."""
+    L = len(chs) - 1
+    for cp1 in cp1s:
+        rp = [0] * 4
+        tot = 0
+        for l in range(1, L - 1):
+            cand = []
+            for r in range(0, 64, 4):
+                rr = list(rp)
+                rr[l] = r
+                cand.append((layer_wave(Net(f, chs, tuple(rr), 0, cp1), l)[0], r))
+            c, rp[l] = min(cand)
+            tot += c
+        cand = []
+        for r3 in range(0, 64, 4):
+            for pp in range(0, 64, 4):
+                rr = list(rp)
+                rr[L - 1] = r3
+                n = Net(f, chs, tuple(rr), pp, cp1)
+                ev = max(n.in_per(l) for l in range(0, L, 2))
+                od = max(n.in_per(l) for l in range(1, L, 2))
+                cand.append((layer_rows4(n, L - 1, ev + od + pp)[0], r3 + pp, r3, pp, ev + od + pp))
+        c, _, rp[L - 1], pp, stride = min(cand)
+        n = Net(f, chs, tuple(rp), pp, cp1)
+        lds = 4 * stride * 4 + 4 * (16 * n.ldw(0) + 48)
+        print(name, "cp1", cp1, "rp", rp, "pp", pp, "cycles", tot + c, "patch floats", stride, "LDS bytes", lds)
+
+
+def cnn3():
+    search3("Aid f=24", 24, [3, 16, 32, 64, 128])
+    search3("Aid f=32", 32, [3, 16, 32, 64, 128])
+
+
 if __name__ == "__main__":
-    {"gemm": gemm, "cnn": cnn}[sys.argv[1] if len(sys.argv) > 1 else "gemm"]()
+    {"gemm": gemm, "cnn": cnn, "cnn3": cnn3}[sys.argv[1] if len(sys.argv) > 1 else "gemm"]()
