@@ -284,3 +284,44 @@ def test_png_folder_loader_rate(device, tmp_path):
     print(json.dumps(rec))
     # more decode processes must not be slower than the training thread decoding alone
     assert max(v for k, v in rec.items() if k.startswith("workers_") and k != "workers_0") >= 0.8 * rec["workers_0"]
+
+
+# ---- cnn_fwd3 (AidCnn) against the general fused kernel: ragged groups, uint8 pixels --------------------
+@pytest.mark.parametrize("f, shape", [(24, (3, 96, 96)), (32, (3, 128, 128))])
+@pytest.mark.parametrize("u8", [False, True])
+def test_aid_forward_kernel_equals_the_general_kernel(device, f, shape, u8):
+    """The workgroup-per-4-patches AidCnn kernel on R = 3 x 3 = 9 patches (a ragged last group) and on
+    R = 4 x 5 = 20, float and uint8 images: same features, saved conv outputs and GroupNorm
+    statistics as cnn_fwd_kernel (knob cnn_fwd3 = 0), and both within 1e-5 of the oracle's features."""
+    from marlclassification_amd import engine as E
+    from marlclassification_amd.engine import HipEngine
+    from tests.util import model_spec, uniform_params
+
+    cfg = mo.OracleConfig("aid", f, 32, 32, 8, 12, 8, 5, 48, 48, actions=[[3, 0], [-3, 0], [0, 3], [0, -3]])
+    params = uniform_params(cfg, 5)
+    for na, nb in ((3, 3), (4, 5)):
+        ns = 2
+        gen = th.Generator().manual_seed(21)
+        img = th.randint(0, 256, (nb, *shape), dtype=th.uint8, generator=gen) if u8 else th.rand(nb, *shape, generator=gen)
+        inp = mo.draw_episode_inputs(cfg, na, nb, ns, shape[1:], 13)
+        got = {}
+        for knob in (1, 0):
+            E.tune("cnn_fwd3", knob)
+            try:
+                eng = HipEngine(model_spec(cfg), device)
+                eng.configure(na, nb, ns, shape, img_u8=u8)
+                eng.pack({k: v.to(device) for k, v in params.items()})
+                args = [t.to(device) for t in (img, inp.pos0, inp.h0, inp.c0, inp.hc0, inp.cc0, inp.q)]
+                out = eng.episode_forward(*args, None, True)
+                got[knob] = (out.step_preds.clone(), [eng.debug_buffer("U", t)[:, : cfg.nf].clone() for t in range(ns)],
+                             out.step_pos.clone())
+            finally:
+                E.tune("cnn_fwd3", 1)
+        assert th.equal(got[1][2], got[0][2])
+        for a, b in zip(got[1][1], got[0][1]):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+        assert (got[1][0] - got[0][0]).abs().max().item() <= 1e-5
+        ref = mo.run_episode(params, cfg, img.float() / 255 if u8 else img, inp, ns)
+        for t in range(ns):
+            u = ref.step_u[t].reshape(na * nb, -1)[:, : cfg.nf]
+            assert (got[1][1][t].cpu() - u).abs().max().item() <= 1e-5
