@@ -35,10 +35,15 @@ class _EpisodeFunction(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: HipEngine, img: th.Tensor, draws: EpisodeDraws, names, *params):
+        # every episode owns its saved activations (a training workspace from the engine's pool), so
+        # several rollouts of one model can be alive at once and (loss1 + loss2).backward() works as
+        # with the reference's autograd graph (reference core/episode.py:84)
+        ws = eng.train_ws_acquire()
         out = eng.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0, draws.cc0,
-                                  draws.noise, None, True, rng=draws.rng)
-        ctx.eng = eng
-        ctx.generation = eng.fwd_generation  # the workspace holds THIS episode until the next one
+                                  draws.noise, None, True, rng=draws.rng, ws=ws)
+        ctx.eng, ctx.ws, ctx.img = eng, ws, img
+        ctx.cfg_key = eng._cfg_key
+        ctx.pack_generation = eng.pack_generation
         ctx.names = names
         ctx.shapes = [p.shape for p in params]
         ctx.mark_non_differentiable(out.step_pos, out.step_actions)
@@ -47,8 +52,20 @@ class _EpisodeFunction(th.autograd.Function):
     @staticmethod
     def backward(ctx, g_preds, g_logp, g_values, _g_pos, _g_act):
         eng: HipEngine = ctx.eng
+        if ctx.ws is None:
+            raise RuntimeError("this episode's saved activations were already released by an earlier "
+                               "backward (run the episode again instead of retain_graph)")
+        if ctx.pack_generation != eng.pack_generation:
+            raise RuntimeError("the model's weights were modified (re-packed) after this episode's rollout: "
+                               "its backward needs the weights the rollout used - call backward before "
+                               "the optimiser step")
+        if ctx.cfg_key != eng._cfg_key:  # another shape ran in between: switch the engine back
+            na, nb, ns, shape, u8 = ctx.cfg_key
+            eng.configure(na, nb, ns, shape, img_u8=u8)
         grads = {k: th.empty(s, device=eng.device) for k, s in zip(ctx.names, ctx.shapes)}
-        eng.episode_backward(g_preds, g_logp, g_values, grads, generation=ctx.generation)
+        eng.episode_backward(g_preds, g_logp, g_values, grads, ws=ctx.ws, img=ctx.img)
+        eng.train_ws_release(ctx.ws)
+        ctx.ws = None
         return (None, None, None, None) + tuple(grads[k] for k in ctx.names)
 
 

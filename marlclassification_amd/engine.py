@@ -185,6 +185,8 @@ class HipEngine:
         # its activations, `_fwd_img` keeps its image batch alive (the first convolution's weight
         # gradient re-gathers the patches), `fwd_generation` lets callers detect a stale backward
         self.fwd_generation = 0
+        self.pack_generation = 0       # bumped by pack(): a live episode's backward needs ITS weights
+        self._ws_pool: Dict[tuple, list] = {}  # released per-episode training workspaces (autograd path)
         self._fwd_img: Optional[th.Tensor] = None
         self._fwd_key: Optional[Tuple] = None
 
@@ -226,6 +228,27 @@ class HipEngine:
             self._ews[key] = ws
         return ws
 
+    def train_ws_acquire(self) -> th.Tensor:
+        """A training workspace owned by ONE episode (the autograd path: several rollouts of the same
+        model may be alive at once, as with the reference's autograd graph - core/episode.py:84 there).
+        Released workspaces of the current configuration are reused; the fused Trainer keeps using
+        the engine's own workspace (``episode_ws``)."""
+        key = (self._cfg_key, _tune_epoch)
+        for k in [k for k in self._ws_pool if k != key]:
+            del self._ws_pool[k]  # other shape / layout: free the memory
+        free = self._ws_pool.setdefault(key, [])
+        if free:
+            return free.pop()
+        _, eb = self._sizes(True)
+        ws = th.zeros(eb // 4 + 64, dtype=th.float32, device=self.device)
+        ws._marl_key = key
+        return ws
+
+    def train_ws_release(self, ws: th.Tensor) -> None:
+        key = getattr(ws, "_marl_key", None)
+        if key == (self._cfg_key, _tune_epoch) and len(self._ws_pool.setdefault(key, [])) < 2:
+            self._ws_pool[key].append(ws)
+
     def _table(self, tensors: Dict[str, th.Tensor]) -> "C.Array":
         arr = (C.c_void_p * MARL_NPARAMS)()
         for name, slot in self.slots.items():
@@ -241,12 +264,14 @@ class HipEngine:
         assert self.cfg is not None, "configure() first"
         check(self.lib.marl_pack_weights(C.byref(self.cfg), self._table(params),
                                          self.weights_ws().data_ptr(), _stream(self.device)))
+        self.pack_generation += 1
 
     def episode_forward(
         self, img: th.Tensor, pos0: th.Tensor, h0: th.Tensor, c0: th.Tensor, hc0: th.Tensor,
         cc0: th.Tensor, noise: Optional[th.Tensor], forced_actions: Optional[th.Tensor] = None,
         train: bool = True, rng: Optional[Tuple[int, int]] = None,
         out: Optional[EpisodeTensors] = None, counters: Optional[th.Tensor] = None,
+        ws: Optional[th.Tensor] = None,
     ) -> EpisodeTensors:
         """``noise`` = injected Exp(1) draws [Ns,Na,Nb,nA] (parity mode); ``noise=None`` with
         ``rng=(seed, offset)`` draws them inside the sampling kernel (perf mode)."""
@@ -268,12 +293,13 @@ class HipEngine:
         if out is None:  # (graph capture passes persistent output tensors: nothing may allocate)
             out = self.new_outputs()
         check(self.lib.marl_episode_forward(
-            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(train).data_ptr(),
+            C.byref(cfg), self.weights_ws().data_ptr(),
+            (ws if ws is not None else self.episode_ws(train)).data_ptr(),
             img.data_ptr(), pos0.data_ptr(), h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(),
             cc0.data_ptr(), _ptr(noise), _ptr(forced_actions), seed & _U64, offset & _U64,
             _ptr(counters), out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
             out.step_pos.data_ptr(), out.step_actions.data_ptr(), int(train), _stream(dev)))
-        if train:
+        if train and ws is None:  # (an episode with its own workspace does not touch the engine's)
             self.fwd_generation += 1
             self._fwd_img = img
             self._fwd_key = self._cfg_key
@@ -295,12 +321,25 @@ class HipEngine:
         self, g_preds: Optional[th.Tensor], g_logp: Optional[th.Tensor],
         g_values: Optional[th.Tensor], grads: Dict[str, th.Tensor],
         generation: Optional[int] = None,
+        ws: Optional[th.Tensor] = None, img: Optional[th.Tensor] = None,
     ) -> None:
         """Backward of the LAST training rollout.  `generation` (the value of
         ``fwd_generation`` right after that rollout) makes a stale call fail loudly: the saved
         activations live in the single training workspace, which a later rollout overwrites."""
         cfg = self.cfg
         assert cfg is not None
+        if ws is not None:  # an episode that owns its workspace (autograd path)
+            if getattr(ws, "_marl_key", None) != (self._cfg_key, _tune_epoch) or img is None:
+                raise RuntimeError(
+                    "episode_backward: the engine was re-configured (other batch size / image shape / "
+                    "layout knob) since this episode's rollout - its workspace no longer fits")
+            gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
+            gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
+            gv = None if g_values is None else _need(g_values, th.float32, "g_values")
+            check(self.lib.marl_episode_backward(
+                C.byref(cfg), self.weights_ws().data_ptr(), ws.data_ptr(), img.data_ptr(), _ptr(gp),
+                _ptr(gl), _ptr(gv), self._table(grads), _stream(self.device)))
+            return
         if self._fwd_img is None or self._fwd_key != self._cfg_key:
             raise RuntimeError(
                 "episode_backward without a matching training rollout: the engine was "

@@ -262,3 +262,57 @@ def test_cli_train_test_infer_on_an_image_folder(device, tmp_path, monkeypatch, 
           f"--class2idx {out / 'class_to_idx.json'} -o {inf_out}").split())
     assert (inf_out / "img0.png" / "animated_gif.gif").exists()
     assert (inf_out / "img3.png" / "pred_step_0.png").exists() and (inf_out / "img3.png" / "info.txt").exists()
+
+
+def test_two_live_episodes_accumulate_like_autograd(device):
+    """The reference's autograd lets ``(loss1 + loss2).backward()`` run over two ``run_episode`` calls of one
+    model (core/episode.py:84 there keeps every rollout's graph alive).  Every episode here owns its
+    saved activations, so: two rollouts (different draws, different batch sizes), ONE backward of the
+    summed loss == the sum of the two separate gradients, in either order; a backward after the
+    weights moved is refused."""
+    g = Golden("g1_conftest")
+    model, sampler = _golden_sampler(g, device)
+    from marlclassification_amd.fused import EpisodeDraws
+
+    img, y = g.img.to(device), g.y.to(device)
+    i = g.inp
+    d_all = sampler.fixed_draws
+    d_7 = EpisodeDraws(*(t.to(device).contiguous() for t in (i.pos0[:, 5:12], i.h0[:, 5:12], i.c0[:, 5:12],
+                                                            i.hc0[:, 5:12], i.cc0[:, 5:12], i.q[:, :, 5:12])))
+
+    def episode(small):
+        sampler.fixed_draws = d_7 if small else d_all
+        return sampler.run_episode(img[5:12] if small else img)
+
+    def grads_of(fn):
+        model.zero_grad(set_to_none=True)
+        fn()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    def separate():
+        _reference_loss(episode(False), y, g.gamma).backward()
+        _reference_loss(episode(True), y[5:12], g.gamma).backward()
+
+    def summed():
+        o1 = episode(False)
+        o2 = episode(True)  # a second live episode, another batch size
+        (_reference_loss(o1, y, g.gamma) + _reference_loss(o2, y[5:12], g.gamma)).backward()
+
+    def reversed_order():
+        o1 = episode(False)
+        o2 = episode(True)
+        _reference_loss(o2, y[5:12], g.gamma).backward()
+        _reference_loss(o1, y, g.gamma).backward()
+
+    a, b, c = grads_of(separate), grads_of(summed), grads_of(reversed_order)
+    for k in a:
+        scale = a[k].abs().max().item() + 1e-12
+        assert (a[k] - b[k]).abs().max().item() <= 2e-6 * scale, k
+        assert (a[k] - c[k]).abs().max().item() <= 2e-6 * scale, k
+    # stale weights: refuse instead of differentiating through other weights than the rollout used
+    o1 = episode(False)
+    with th.no_grad():
+        next(model.parameters()).add_(1e-3)
+    episode(True)  # (re-packs the modified weights)
+    with pytest.raises(RuntimeError, match="weights were modified"):
+        _reference_loss(o1, y, g.gamma).backward()

@@ -371,17 +371,24 @@ def test_graph_replay_equals_eager_iterations(device, tag):
 
 # ---- a stale backward must fail loudly ------------------------------------------------
 def test_backward_of_an_overwritten_episode_raises(device):
-    from tests.test_gpu_api import _golden_sampler, _reference_loss
+    """The engine-level calls share ONE training workspace (the fused Trainer's path): a backward for a
+    rollout that a later rollout overwrote is refused.  (Episodes run through autograd own their
+    workspace since round 3 - tests/test_gpu_api.py::test_two_live_episodes_accumulate_like_autograd.)"""
+    from tests.test_gpu_api import _golden_sampler
 
     g = Golden("g1_conftest")
     model, sampler = _golden_sampler(g, device)
-    out1 = sampler.run_episode(g.img.to(device))
-    loss1 = _reference_loss(out1, g.y.to(device), g.gamma)
-    out2 = sampler.run_episode(g.img.to(device))  # overwrites the engine's training workspace
+    img = g.img.to(device)
+    eng, out1 = sampler.run_episode_raw(img, True)
+    gen1 = eng.fwd_generation
+    gp, gl, gv, _, _ = eng.a2c_loss(out1, g.y.to(device), g.gamma)
+    eng, out2 = sampler.run_episode_raw(img, True)  # overwrites the engine's training workspace
+    grads = {k: th.empty_like(p) for k, p in model.named_parameters()}
     with pytest.raises(RuntimeError, match="overwritten"):
-        loss1.backward()
-    _reference_loss(out2, g.y.to(device), g.gamma).backward()  # the live episode still works
-    assert all(p.grad is not None and bool(th.isfinite(p.grad).all()) for p in model.parameters())
+        eng.episode_backward(gp, gl, gv, grads, generation=gen1)
+    gp, gl, gv, _, _ = eng.a2c_loss(out2, g.y.to(device), g.gamma)
+    eng.episode_backward(gp, gl, gv, grads, generation=eng.fwd_generation)  # the live episode still works
+    assert all(bool(th.isfinite(v).all()) for v in grads.values())
 
 
 # ---- data-parallel trainer: HIP path + all-reduce + exact standardize, 2 ranks over gloo --------
