@@ -43,7 +43,11 @@ for e in out.values():
 tot_f = sum(c * f for c, f in F.values())
 tot_w = sum(c * W[k][1] for k, (c, _) in F.items() if k in W)
 out["whole_run_2xfetch_plus_write_gb"] = round((2 * tot_f + tot_w) * 1024 / 1e9, 3)
-out["whole_run_iterations"] = 3
+# iterations in the profiled command: 1 warm-up + 2 timed + one per kernel class of the sweep
+lstm = next((c for k, (c, _) in F.items() if k.startswith(("gemm_nt_split_kernel<128, true", "gemm_nt_kernel<128, 128, 4, 1, true"))), 0)
+out["whole_run_iterations"] = lstm // 16 if lstm else None  # (the LSTM kernel runs once per step, 16 steps)
+if lstm:
+    out["per_iteration_2xfetch_plus_write_gb"] = round(out["whole_run_2xfetch_plus_write_gb"] / (lstm // 16), 3)
 out["src_sha256"] = csrc_sha256()
 out["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (two separate passes) -- python3 "
                  "bench.py --steps 2 --warmup 1 --no-cpu-baseline; per-launch averages per kernel class; summaries in "
