@@ -398,12 +398,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(const GemmBatch b
 // A thread stages one 4 x 4 block (4 rows x 4 columns) of each operand per tile and transposes
 // it in registers: LDS row = matrix column, 4 consecutive rows r = 8 bytes of a plane.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
+// NW = 4: a thread stages one block of EACH operand, a wave owns 64 x 64 of the tile.  NW = 8 (512
+// threads): threads 0..255 stage A, 256..511 stage B (half the staging registers), a wave owns
+// 32 x 64 - twice the waves per SIMD to cover barrier and operand latency.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_tn_split_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
     float* __restrict__ out, int ldo, int64_t out_split_stride, int NI, int NJ, int64_t rows,
     int64_t rows_per_split, float* __restrict__ csum, int gx, int gy, int gz) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int BM = 128, BN = 128, WMn = NW / 2, TM = BM / WMn / 32, TN = 2;
+    constexpr bool HALF = NW == 8;  // one operand per thread
     constexpr int APL = BM * SROW, BPL = BN * SROW;
+    static_assert(APL == BPL, "shared plane stride");
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* const As = smem_c;
     char* const Bs = smem_c + 3 * APL;
@@ -431,16 +437,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
 
     // block of this thread: tile rows [4 rb, +4), columns [4 cb, +4) (clamped into the padded
     // width; columns past NI / NJ are never stored)
-    const int rb = tid & 7, cb = tid >> 3;
+    const int st = tid & 255;
+    const bool isB = HALF && tid >= 256;
+    const int rb = st & 7, cb = st >> 3;
     const int ic = i0 + 4 * cb, jc = j0 + 4 * cb;
     const uint32_t acol = (uint32_t)(ic < NI4 ? ic : NI4 - 4) * 4u;
     const uint32_t bcol = (uint32_t)(jc < NJ4 ? jc : NJ4 - 4) * 4u;
     const char* abase = reinterpret_cast<const char*>(A + (size_t)r_begin * lda);
     const char* bbase = reinterpret_cast<const char*>(B + (size_t)r_begin * ldb);
-    const bool do_csum = csum != nullptr && by == 0;
+    if (HALF && isB) {  // this thread's ONE operand goes through the "a" names below
+        abase = bbase;
+        lda = ldb;
+    }
+    const uint32_t col1 = isB ? bcol : acol;
+    const bool do_csum = csum != nullptr && by == 0 && !isB;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 raX[4], rbX[4], raY[4], rbY[4];
+    float4 raX[4], rbX[HALF ? 1 : 4], raY[4], rbY[HALF ? 1 : 4];
     float mX[4] = {1.f, 1.f, 1.f, 1.f}, mY[4] = {1.f, 1.f, 1.f, 1.f};
     bool maskedX = false, maskedY = false;
     // unconditional loads; tiles past the end re-read the last tile; rows past r_end are clamped
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
     {                                                                                      \
         const bool live_ = (tile_) < T;                                                    \
         abase -= live_ ? (size_t)0 : (size_t)SK * lda * 4;                                 \
-        bbase -= live_ ? (size_t)0 : (size_t)SK * ldb * 4;                                 \
+        if (!HALF) bbase -= live_ ? (size_t)0 : (size_t)SK * ldb * 4;                      \
         const int64_t base_ = r_begin + (int64_t)(live_ ? (tile_) : T - 1) * SK;           \
         masked_ = base_ + SK > r_end;                                                      \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
@@ -459,15 +472,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
                 rr_ = (int)(r_end - 1 - base_);                                            \
                 m_[q] = 0.f;                                                               \
             }                                                                              \
-            ra_[q] = *reinterpret_cast<const float4*>(abase + ((uint32_t)rr_ * (uint32_t)lda * 4u + acol)); \
-            rb_[q] = *reinterpret_cast<const float4*>(bbase + ((uint32_t)rr_ * (uint32_t)ldb * 4u + bcol)); \
+            ra_[q] = *reinterpret_cast<const float4*>(abase + ((uint32_t)rr_ * (uint32_t)lda * 4u + col1)); \
+            if (!HALF)                                                                     \
+                rb_[HALF ? 0 : q] = *reinterpret_cast<const float4*>(bbase + ((uint32_t)rr_ * (uint32_t)ldb * 4u + bcol)); \
         }                                                                                  \
         abase += (size_t)SK * lda * 4;                                                     \
-        bbase += (size_t)SK * ldb * 4;                                                     \
+        if (!HALF) bbase += (size_t)SK * ldb * 4;                                          \
     }
 #define MARL_TS_STORE(ra_, rb_, m_, masked_)                                               \
     {                                                                                      \
-        if (masked_) {                                                                     \
+        if (masked_) { /* (both operands zeroed: with one operand per thread either would do) */ \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                \
                 ra_[q].x *= m_[q];                                                         \
                 ra_[q].y *= m_[q];                                                         \
@@ -481,19 +495,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
             cs.z += (ra_[0].z + ra_[1].z) + (ra_[2].z + ra_[3].z);                         \
             cs.w += (ra_[0].w + ra_[1].w) + (ra_[2].w + ra_[3].w);                         \
         }                                                                                  \
-        char* da_ = As + (4 * cb) * SROW + rb * 8;                                         \
-        char* db_ = Bs + (4 * cb) * SROW + rb * 8;                                         \
+        char* da_ = (isB ? Bs : As) + (4 * cb) * SROW + rb * 8;                            \
         split_store4(da_, APL, ra_[0].x, ra_[1].x, ra_[2].x, ra_[3].x);                    \
         split_store4(da_ + SROW, APL, ra_[0].y, ra_[1].y, ra_[2].y, ra_[3].y);             \
         split_store4(da_ + 2 * SROW, APL, ra_[0].z, ra_[1].z, ra_[2].z, ra_[3].z);         \
         split_store4(da_ + 3 * SROW, APL, ra_[0].w, ra_[1].w, ra_[2].w, ra_[3].w);         \
-        split_store4(db_, BPL, rb_[0].x, rb_[1].x, rb_[2].x, rb_[3].x);                    \
-        split_store4(db_ + SROW, BPL, rb_[0].y, rb_[1].y, rb_[2].y, rb_[3].y);             \
-        split_store4(db_ + 2 * SROW, BPL, rb_[0].z, rb_[1].z, rb_[2].z, rb_[3].z);         \
-        split_store4(db_ + 3 * SROW, BPL, rb_[0].w, rb_[1].w, rb_[2].w, rb_[3].w);         \
+        if (!HALF) {                                                                       \
+            char* db_ = Bs + (4 * cb) * SROW + rb * 8;                                     \
+            split_store4(db_, BPL, rb_[0].x, rb_[HALF ? 0 : 1].x, rb_[HALF ? 0 : 2].x, rb_[HALF ? 0 : 3].x); \
+            split_store4(db_ + SROW, BPL, rb_[0].y, rb_[HALF ? 0 : 1].y, rb_[HALF ? 0 : 2].y, rb_[HALF ? 0 : 3].y); \
+            split_store4(db_ + 2 * SROW, BPL, rb_[0].z, rb_[HALF ? 0 : 1].z, rb_[HALF ? 0 : 2].z, rb_[HALF ? 0 : 3].z); \
+            split_store4(db_ + 3 * SROW, BPL, rb_[0].w, rb_[HALF ? 0 : 1].w, rb_[HALF ? 0 : 2].w, rb_[HALF ? 0 : 3].w); \
+        }                                                                                  \
     }
 
-    const char* al = As + (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
+    const char* al = As + (wm * (BM / WMn) + (lane & 31)) * SROW + (lane >> 5) * 16;
     const char* bl = Bs + (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 16;
 
     if (T > 0) {
@@ -522,10 +538,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
 #undef MARL_TS_LOAD
 #undef MARL_TS_STORE
 
-    if (do_csum) {  // the 8 threads rb = 0..7 of a column block staged the same 4 columns
+    if (csum != nullptr && by == 0) {  // the 8 threads rb = 0..7 of a column block staged the same 4 columns
         __syncthreads();
         float4* sh4 = reinterpret_cast<float4*>(smem_c);
-        sh4[rb * 32 + cb] = cs;
+        if (!isB) sh4[rb * 32 + cb] = cs;
         __syncthreads();
         if (tid < 32) {
             float4 t = sh4[tid];
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(
             if (col >= NJ) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                const int row = i0 + wm * (BM / WMn) + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
                 if (row < NI) o[(size_t)row * ldo + col] = acc[i][j][r];
             }
         }
@@ -690,8 +706,12 @@ int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStre
 int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
                          int64_t stride, int ni, int nj, int64_t rows, int64_t rows_per_split,
                          float* csum, dim3 grid, int gx, int gy, int gz, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(256), (size_t)3 * 256 * SROW, st, a, lda, b, ldb,
-                       out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
+    if (tune_get("tn_split_waves", 8) == 8)
+        hipLaunchKernelGGL(gemm_tn_split_kernel<8>, grid, dim3(512), (size_t)3 * 256 * SROW, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
+    else
+        hipLaunchKernelGGL(gemm_tn_split_kernel<4>, grid, dim3(256), (size_t)3 * 256 * SROW, st, a, lda, b, ldb,
+                           out, ldo, stride, ni, nj, rows, rows_per_split, csum, gx, gy, gz);
     return MARL_OK;
 }
 

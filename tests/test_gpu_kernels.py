@@ -92,8 +92,14 @@ def test_gemm_nt_is_transpose_detecting(device, mfma_split):
 @pytest.mark.parametrize("rows,ni,nj", [(665, 92, 183), (5000, 16, 27), (20000, 200, 130),
                                         (33, 1, 24), (70000, 8, 9), (4096, 1024, 368),
                                         (9001, 300, 257), (65536, 384, 256)])
-def test_gemm_tn(device, mfma_split, rows, ni, nj):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_gemm_tn(device, mfma_split, rows, ni, nj, waves):
+    """waves: 8 = the 512-thread form of the bf16x6 kernel (one operand per thread while staging,
+    32 x 64 per wave; the default), 4 = the 256-thread form (knob tn_split_waves)."""
     lib, check = _lib()
+    if waves == 4 and not mfma_split:
+        pytest.skip("the fp32-MFMA kernel has one form")
+    check(lib.marl_tune(b"tn_split_waves", waves))
     g = th.Generator().manual_seed(rows + ni + nj)
     a = th.randn(rows, ni, generator=g)
     b = th.randn(rows, nj, generator=g)
@@ -112,6 +118,7 @@ def test_gemm_tn(device, mfma_split, rows, ni, nj):
     check(lib.marl_gemm_tn(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1], cd2.data_ptr(),
                            ldc, ni, nj, rows, scratch.data_ptr(), sb, None))
     assert th.equal(cd, cd2)
+    check(lib.marl_tune(b"tn_split_waves", 8))
 
 
 @pytest.mark.parametrize("m,n", [(95, 24), (4096, 384), (7, 1), (300, 1000)])
