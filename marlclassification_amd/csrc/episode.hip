@@ -485,6 +485,8 @@ struct Ctx {
     int train;
     RedQueue* rq = nullptr;  // backward: deferred reductions (null: every reduction launches at once)
     bool defer_slabs = false;  // also the split-K / conv weight-gradient slabs (tens of MB each)
+    size_t defer_small = 0;    // ... or only those of at most this many bytes (they stay in the L2)
+    bool defer_this(size_t slab_bytes) const { return defer_slabs || (defer_small && slab_bytes <= defer_small); }
 
     const float* wp(int i) const { return W + w.wp[i]; }
     const float* wt(int i) const { return W + w.wt[i]; }
@@ -1056,7 +1058,8 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
 static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, int pidx, int ni,
               int nj, int64_t rows, float* bias = nullptr) {
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
-                          c.e.tns_bytes, c.st, bias, c.defer_slabs ? c.rq : nullptr);
+                          c.e.tns_bytes, c.st, bias,
+                          c.defer_this(gemm_tn_scratch_bytes(ni, nj, rows)) ? c.rq : nullptr);
 }
 // scratch for `blocks` affine partial rows of width 2n: the queue's when the reduction can wait
 static float* part_scratch(const Ctx& c, int64_t blocks, int n, int acc, RedQueue*& q) {
@@ -1100,10 +1103,14 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     rq.reset(c.at(c.e.RED), c.e.red_floats, c.st);
     // 1: the small LayerNorm / GroupNorm affine partials wait for one launch at the end; the
     // weight-gradient slabs (~0.4 GB per iteration in all) are reduced at once, while the
-    // Infinity Cache still holds them (2: defer those too - measured slower)
-    const int defer = tune_get("red_defer", 1);
+    // Infinity Cache still holds them (2: defer those too - measured slower at C3 / C4: 0.43 GB of
+    // slabs come back from HBM).  3 (default): as 1, plus the slabs of at most red_defer_kb KB
+    // each (8 MB: larger thresholds lose again at C4) - on small problems (C2: 22 weight gradients) one batched
+    // reduction replaces 22 launches: 0.953 -> 0.897 ms per iteration.
+    const int defer = tune_get("red_defer", 3);
     if (defer) c.rq = &rq;
-    c.defer_slabs = defer > 1;
+    c.defer_slabs = defer == 2;
+    c.defer_small = defer == 3 ? (size_t)tune_get("red_defer_kb", 8192) * 1024 : 0;
     const Dims& d = c.d;
     hipStream_t st = c.st;
     const int64_t NR = d.NR;
@@ -1449,7 +1456,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                 }
                 // per-workgroup slabs; the launcher places part_b behind the weight slabs
                 w.part_w = c.at(c.e.TNS);
-                if (c.rq && c.defer_slabs) {
+                if (c.rq && c.defer_this((size_t)cnn_wgrad_blocks(w) * ((size_t)co * d.K[l] + co) * sizeof(float))) {
                     float* p = c.rq->take((size_t)cnn_wgrad_blocks(w) * ((size_t)co * d.K[l] + co));
                     if (c.rq->rc == MARL_OK) w.part_w = p;
                 }
