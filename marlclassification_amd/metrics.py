@@ -1,5 +1,5 @@
 """Windowed meters (reference metrics.py) kept ON THE DEVICE: ``add`` enqueues a tiny
-bincount and never synchronises; the host only reads values when asked (``precision()``,
+scatter-add and never synchronises; the host only reads values when asked (``precision()``,
 ``recall()``, ``loss()``), i.e. every ``log_interval`` iterations instead of 4-5 ``.item()``
 syncs per iteration (reference training/trainer.py:119-135).  Reporting code, not on the
 timed path."""
@@ -26,7 +26,11 @@ class ConfusionMeter:
     def add(self, y_proba: th.Tensor, y_true: th.Tensor) -> None:
         y_pred = y_proba.argmax(dim=1)
         idx = y_true.to(y_pred.device) * self.__nb_class + y_pred
-        self.__window.append(th.bincount(idx, minlength=self.__nb_class**2))
+        # (not th.bincount: on the GPU it reads the maximum back to size its output - a device
+        # synchronisation per training iteration, measured 9.4 vs 8.0 ms per C3 iteration)
+        counts = th.zeros(self.__nb_class**2, dtype=th.long, device=idx.device)
+        counts.scatter_add_(0, idx, th.ones_like(idx))
+        self.__window.append(counts)
 
     def conf_mat(self) -> th.Tensor:
         if not self.__window:
