@@ -963,9 +963,7 @@ __device__ __forceinline__ void fwd3_layer(const CnnFwdArgs& A, float* lds, int 
     constexpr int P = N::P(l), cin = N::cin(l), cout = N::cout(l), K = N::K(l), hout = N::hout(l), G = N::grp(l);
     constexpr int cpg = N::cpg(l), rs = N::rs(l), cs = N::cs(l), steps = N::steps(l);
     constexpr int MT = N::mt(l), NT = N::nt(l), PB = PL::pb(l), NTASK = PL::ntask(l);
-    constexpr int KB = PL::kb(l), NBLK = PL::nblk(l);
     static_assert(l == 0 || KB0 == steps, "one fragment per K step");
-    (void)NBLK;
     constexpr bool last = l + 1 == N::L;
     constexpr int ln = last ? 0 : l + 1;  // the region zeroed during this layer: next image / next group's input
     constexpr int rs_n = N::rs(ln), cs_n = N::cs(ln);
