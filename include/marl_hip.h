@@ -244,6 +244,34 @@ size_t marl_gemm_weight_image_bytes(int n, int k);
 int marl_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc,
                  int ni, int nj, int64_t rows, float* scratch, size_t scratch_bytes, void* stream);
 size_t marl_gemm_tn_scratch(int ni, int nj, int64_t rows);
+/* ---- image GEMMs (csrc/gemm3.hip): the form the episode uses for its large products ----
+ * A "k16 image" of an fp32 matrix [rows][k] is [rows][ceil(k/16)][3][16] bf16: every element split
+ * into three bf16 terms x0 + x1 + x2 == x, K zero-padded to a whole 16-deep step (96 bytes per row
+ * and step).  marl_image_build makes one from an fp32 matrix (ld >= k); inside the episode the
+ * PRODUCER kernels write the images of their outputs directly.  16-byte aligned. */
+size_t marl_image_bytes(int64_t rows, int k);
+int marl_image_build(const float* src, int ld, int64_t rows, int k, void* image, void* stream);
+/* C[M,N] (+)= A * B^T + bias from the images of A [M,K] and B [N,K] (six bf16 MFMA products per fp32
+ * product, fp32 accumulation - same arithmetic as marl_gemm_nt with mfma_split = 1).
+ * variant: 0 = automatic tile plan (1 / 2 / 3 force 256x128, 128x128, 128x64 tiles - tools only). */
+int marl_gemm_nt_images(const void* a3, const void* b3, const float* bias, float* c, int ldc, int m, int n,
+                        int k, int accumulate, int variant, void* stream);
+int marl_gemm_nt_images_batch(int count, const void* const* a3, const void* const* b3, float* const* c,
+                              const int* n, const int* ldc, int m, int k, int accumulate, int variant,
+                              void* stream);
+/* nn.LSTMCell (networks/recurrent.py:19-35) from images: gates = U * W_ih^T + H * W_hh^T + bias (rows of
+ * the weight images g * n + unit, g = i,f,g,o; bias = b_ih + b_hh), c' = s(f) c + s(i) tanh(g),
+ * h' = s(o) tanh(c'); gates (nullable) receives the activated gates [M, ld_gates]; h3_next (nullable)
+ * the image of h'. */
+int marl_lstm_images(const void* u3, int nin, const void* h3, const void* wih3, const void* whh3,
+                     const float* bias, const float* c_prev, float* h_next, float* c_next, float* gates,
+                     void* h3_next, int m, int n, int ld_state, int ld_gates, int variant, int cells,
+                     void* stream);
+/* C[NI,NJ] = sum_r A[r,i] * B[r,j] from the images of A [rows,NI] and B [rows,NJ] (rows % 32 == 0);
+ * colsum (nullable) [NI] = column sums of A (the matching bias gradient). */
+size_t marl_gemm_tn_images_scratch(int ni, int nj, int64_t rows);
+int marl_gemm_tn_images(const void* a3, const void* b3, float* c, int ldc, int ni, int nj, int64_t rows,
+                        float* colsum, float* scratch, size_t scratch_bytes, void* stream);
 int marl_ln_silu_fwd(const float* z, int ldz, const float* gamma, const float* beta,
                      float* out, int ldo, float* stats, int m, int n, void* stream);
 

@@ -70,7 +70,8 @@ EXPORTS = (
     "marl_profile_begin marl_profile_end marl_normalize_positions "
     "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_tune_get marl_draw_episode "
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
-    "marl_graph_destroy"
+    "marl_graph_destroy marl_image_bytes marl_image_build marl_gemm_nt_images marl_gemm_nt_images_batch "
+    "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -114,6 +115,16 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_gemm_tn_scratch.restype = _sz
     lib.marl_gemm_tn_scratch.argtypes = [_i, _i, _i64]
     lib.marl_ln_silu_fwd.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]
+    lib.marl_image_bytes.restype = _sz
+    lib.marl_image_bytes.argtypes = [_i64, _i]
+    lib.marl_image_build.argtypes = [_vp, _i, _i64, _i, _vp, _vp]
+    lib.marl_gemm_nt_images.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.marl_gemm_nt_images_batch.argtypes = [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i),
+                                              C.POINTER(_i), _i, _i, _i, _i, _vp]
+    lib.marl_gemm_tn_images_scratch.restype = _sz
+    lib.marl_gemm_tn_images_scratch.argtypes = [_i, _i, _i64]
+    lib.marl_gemm_tn_images.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]
+    lib.marl_lstm_images.argtypes = [_vp, _i] + [_vp] * 9 + [_i] * 6 + [_vp]
     lib.marl_cnn_wgrad.argtypes = ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64] + [_i] * 8 +
                                    [_vp, _vp, _vp, _sz, _vp])
     lib.marl_cnn_wgrad_scratch.restype = _sz

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "../../include/marl_hip.h"
+#include "split.h"
 
 namespace marl {
 
@@ -154,6 +155,83 @@ int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float
                          int64_t stride, int ni, int nj, int64_t rows, int64_t rows_per_split,
                          float* csum, dim3 grid, int gx, int gy, int gz, hipStream_t st);
 
+// ---------------------------------------------------------------------------
+// Image GEMMs (gemm3.hip): both operands are k16 images (split.h) written by their producers
+// ---------------------------------------------------------------------------
+struct G3Seg {
+    const char* a3;  // image of A (split.h: [row / 32][step][row % 32][96 bytes]); the product's row 0 is
+    const char* b3;  // image row a_row0 / b_row0 (multiples of 32 keep the operand stream contiguous)
+    int a_row0, b_row0;
+    int steps;       // 16-deep K steps of both images (= K steps of this segment)
+};
+struct G3Prob {
+    G3Seg seg[2];
+    int nseg;
+    int m, n;
+    float* c;
+    int ldc;
+    const float* bias;
+    int accumulate;
+    // fused LSTM-cell epilogue (as GemmProb) + the image of h_next
+    const float* c_prev;
+    float* h_next;
+    float* c_next;
+    float* gates;
+    int ld_state, ld_gates;
+    char* h3;  // nullable; image of h_next with h3_steps steps, the product's row 0 = image row h3_row0
+    int h3_row0, h3_steps;
+};
+constexpr int kMaxG3 = 4;
+struct G3Batch {
+    G3Prob p[kMaxG3];
+    int count;
+    int gx, gy, xcd_map;  // filled by the launcher
+    int safe;             // debug: every step fully waited for (bit-identical results, no overlap)
+#ifdef MARL_G3_ABLATE
+    long long* clk;       // perf diagnosis: cycle / wall-clock counters of workgroup 0
+#endif
+};
+G3Prob g3_prob(const void* a3, int a_row0, const void* b3, int b_row0, int k, float* c, int ldc, int m, int n,
+               const float* bias = nullptr, int accumulate = 0);
+void g3_add_seg(G3Prob& p, const void* a3, int a_row0, const void* b3, int b_row0, int k);
+int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant = 0);
+int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant = 0);
+// weight-gradient form: contraction over the ROWS of two images (gemm_tn3_kernel)
+struct G3TnArgs {
+    const char* a3;
+    const char* b3;
+    int a_steps, b_steps;  // 16-column steps of each image (its row-block stride / 3072)
+    int a_row0, b_row0;    // image row of contraction row 0 (multiples of 32)
+    float* out;            // [splits][ni][ldo] partial slabs
+    int ldo;
+    int64_t out_split_stride;
+    int ni, nj;
+    int64_t rows, rows_per_split;
+    float* csum;           // nullable: [splits][ni] column sums of A
+    int gx, gy, gz, safe;  // filled by the launcher
+};
+struct G3TnPlan {
+    int variant, splits;
+    int64_t rows_per_split;
+};
+G3TnPlan g3_tn_plan(int ni, int nj, int64_t rows);
+size_t g3_tn_scratch_bytes(int ni, int nj, int64_t rows);
+int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st);
+
+// fp32 [rows][ld] (k valid columns) -> its image (rows padded to whole blocks: zeros)
+struct ImgDesc {
+    const float* src;
+    void* dst;
+    int64_t rows;
+    int k, ld;
+};
+constexpr int kMaxImgDesc = 64;
+struct ImgBatch {
+    ImgDesc d[kMaxImgDesc];
+    int count;
+};
+int launch_images(const ImgBatch& b, hipStream_t st);
+
 // per-launch HIP-event timing of one kernel class (see marl_profile_begin); no-ops when off
 constexpr int kProfClasses = 6;
 void prof_before(int cls, hipStream_t st);
@@ -264,6 +342,8 @@ int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w,
 int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
                          const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
                          hipStream_t st);
+struct LstmBwdBatch;
+int launch_lstm_cell_bwd_batch(LstmBwdBatch& b, int count, hipStream_t st);  // 1 or 2 cells, images optional
 int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, float* gates0,
                           int ldg0, const float* cp0, const float* cn0, int ldc0, int n0,
                           const float* dh1, int lddh1, float* dc1, int lddc1, float* gates1,
@@ -423,11 +503,19 @@ struct LstmBwdArgs {
     const float* c_prev;
     const float* c_new;
     int lddh, lddc, ldg, ldc, n;
+    // optional: the k16 image (split.h) of the gate gradients [rows, 4 n] - the A operand of the image
+    // GEMMs that consume them; written by the four-units-per-thread forms only (n % 4 == 0)
+    char* g3;
+    int g3_row0, g3_steps;
 };
 struct LstmBwdBatch {
     LstmBwdArgs a[2];
     int64_t rows;
+    int vec4;  // four consecutive units per thread (16-byte accesses; required for the images)
 };
+inline bool lstm_bwd_vec4_ok(const LstmBwdArgs& a) {
+    return (a.n & 3) == 0 && (a.lddh & 3) == 0 && (a.lddc & 3) == 0 && (a.ldg & 3) == 0 && (a.ldc & 3) == 0;
+}
 // element (r, u) with dL/dh given
 __device__ __forceinline__ void lstm_cell_bwd_at(const LstmBwdArgs& A, int64_t r, int u, float dhv);
 __device__ __forceinline__ void lstm_cell_bwd_elem(const LstmBwdArgs& A, int64_t rows, int64_t idx) {
@@ -448,6 +536,52 @@ __device__ __forceinline__ void lstm_cell_bwd_at(const LstmBwdArgs& A, int64_t r
     g[2 * n] = dcv * gi * (1.0f - gg * gg);
     g[3 * n] = dhv * tc * go * (1.0f - go);
     A.dc[r * A.lddc + u] = dcv * gf;
+}
+
+// four consecutive units (row r, units u .. u + 3, u % 4 == 0) given their dL/dh; same arithmetic
+__device__ __forceinline__ void lstm_cell_bwd_at4(const LstmBwdArgs& A, int64_t r, int u, const float (&dhv)[4]) {
+    const int n = A.n;
+    float* g = A.gates + r * A.ldg + u;
+    const float4 gi4 = *reinterpret_cast<const float4*>(g), gf4 = *reinterpret_cast<const float4*>(g + n),
+                 gg4 = *reinterpret_cast<const float4*>(g + 2 * n), go4 = *reinterpret_cast<const float4*>(g + 3 * n);
+    const float4 cn4 = *reinterpret_cast<const float4*>(A.c_new + r * A.ldc + u),
+                 cp4 = *reinterpret_cast<const float4*>(A.c_prev + r * A.ldc + u),
+                 dc4 = *reinterpret_cast<const float4*>(A.dc + r * A.lddc + u);
+    const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+    const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+    const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+    const float dcin[4] = {dc4.x, dc4.y, dc4.z, dc4.w};
+    float o[5][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float tc = tanhf(cn[q]);
+        const float dcv = dhv[q] * go[q] * (1.0f - tc * tc) + dcin[q];
+        o[0][q] = dcv * gg[q] * gi[q] * (1.0f - gi[q]);
+        o[1][q] = dcv * cp[q] * gf[q] * (1.0f - gf[q]);
+        o[2][q] = dcv * gi[q] * (1.0f - gg[q] * gg[q]);
+        o[3][q] = dhv[q] * tc * go[q] * (1.0f - go[q]);
+        o[4][q] = dcv * gf[q];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(g + k * n) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    *reinterpret_cast<float4*>(A.dc + r * A.lddc + u) = make_float4(o[4][0], o[4][1], o[4][2], o[4][3]);
+    if (A.g3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = k * n + u;
+            img_store4(A.g3 + img_off(A.g3_row0 + r, col >> 4, A.g3_steps), col, o[k][0], o[k][1], o[k][2], o[k][3]);
+        }
+    }
+}
+__device__ __forceinline__ void lstm_cell_bwd_elem4(const LstmBwdArgs& A, int64_t rows, int64_t idx) {
+    const int n4 = A.n >> 2;
+    if (idx >= rows * n4) return;
+    const int64_t r = idx / n4;
+    const int u = (int)(idx - r * n4) * 4;
+    const float4 d = *reinterpret_cast<const float4*>(A.dh + r * A.lddh + u);
+    const float dhv[4] = {d.x, d.y, d.z, d.w};
+    lstm_cell_bwd_at4(A, r, u, dhv);
 }
 
 // backward of the same chain, layers listed from the LAST (output side) to the FIRST
@@ -492,6 +626,9 @@ struct PanelBwdProb {
     int has_cell, panel_blocks;
     LstmBwdArgs cell;
     int64_t cell_rows;
+    int cell_vec4;  // (filled by the launcher) the riding-along cell runs four units per thread
+    // reported by the launcher: the gate-gradient images asked for (cellb.g3 / cell.g3) are written
+    int cellb_img_done, cell_img_done;
 };
 int panel_bwd_blocks(int m);
 int panel_chain_blocks(int na, int nb);  // workgroups of a by_batch launch

@@ -195,10 +195,19 @@ struct WLayout {
     int ldt[MARL_NPARAMS];
     size_t gp[MARL_NPARAMS];  // packed gradient (same shape as wp)
     size_t wp3[MARL_NPARAMS], wt3[MARL_NPARAMS];  // bf16x3 images of wp / wt (gemm_split.hip)
+    size_t wp3k[MARL_NPARAMS], wt3k[MARL_NPARAMS];  // k16 images of wp / wt (gemm3.hip, split.h), 0 = none
     size_t wf[MARL_NPARAMS];  // conv weights in MFMA-fragment order (cnn_fwd3), 0 = none
     size_t bsum_b, bsum_a;    // b_ih + b_hh
     size_t total;
 };
+
+// The image GEMMs (gemm3.hip) take over the large products when every step's row slice starts on an
+// image row block (R % 32 == 0: all BASELINE shapes) and the cells' widths keep 16-byte accesses.
+// (Layout-relevant: the workspaces grow by the images - marl_workspace_sizes after a knob change.)
+static bool g3_enabled(const Dims& d) {
+    return split_mode() && tune_get("g3", 1) != 0 && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32) &&
+           (d.n_b & 3) == 0 && (d.n_a & 3) == 0;
+}
 
 // conv weights whose tiles are whole (16 output channels x 16-deep K steps) get a fragment-order copy
 static bool conv_frag_ok(const ParamMeta& m) { return m.kind == PK_CONV && m.n % 16 == 0 && m.k % 16 == 0; }
@@ -207,7 +216,7 @@ static void make_wlayout(const Dims& d, WLayout& w) {
     Bump b;
     for (int i = 0; i < MARL_NPARAMS; ++i) {
         const ParamMeta m = param_meta(d, i);
-        w.wp[i] = w.wt[i] = w.gp[i] = w.wp3[i] = w.wt3[i] = w.wf[i] = 0;
+        w.wp[i] = w.wt[i] = w.gp[i] = w.wp3[i] = w.wt3[i] = w.wf[i] = w.wp3k[i] = w.wt3k[i] = 0;
         w.ldp[i] = w.ldt[i] = 0;
         if (m.kind == PK_MATRIX || m.kind == PK_CONV) {
             w.ldp[i] = p4(m.k);
@@ -218,6 +227,10 @@ static void make_wlayout(const Dims& d, WLayout& w) {
             if (m.kind == PK_MATRIX) {
                 w.wp3[i] = b.take(split_image_floats(m.n, m.k));
                 w.wt3[i] = b.take(split_image_floats(m.k, m.n));
+                if (g3_enabled(d)) {
+                    w.wp3k[i] = b.take(img_bytes(m.n, m.k) / sizeof(float));
+                    w.wt3k[i] = b.take(img_bytes(m.k, m.n) / sizeof(float));
+                }
             } else if (conv_frag_ok(m)) {
                 b.take(16);  // (offset 0 means "none")
                 w.wf[i] = b.take((size_t)m.n * m.k);
@@ -254,6 +267,8 @@ struct ELayout {
     size_t GPRED, DLOG, DVAL, DAQ1, DAC1, DAP1, DH, DHC, DC, DCC, DDBAR, DDBAR2, DAD1, DMBAR, DZE2, DAE1, DU,
         DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
+    size_t GB3, GA3;  // k16 images of the gate gradients [Ns*R, 4 n] (g3 only; float offsets)
+    bool g3;
     size_t PART, TNS, LOSS;
     size_t RED, red_floats;  // scratch of the deferred-reduction queue (sum over every use)
     size_t part_floats, tns_bytes, loss_floats;
@@ -374,6 +389,12 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
     e.STQ1 = b.take(NR * 2);
     e.AQ1 = b.take(NR * d.ld_nlb);
     e.part_floats = e.tns_bytes = e.loss_floats = 0;
+    e.g3 = g3_enabled(d);
+    e.GB3 = e.GA3 = 0;
+    if (train && e.g3) {
+        e.GB3 = b.take(img_bytes((int64_t)NR, 4 * d.n_b) / sizeof(float));
+        e.GA3 = b.take(img_bytes((int64_t)NR, 4 * d.n_a) / sizeof(float));
+    }
     if (train) {
         e.GPRED = b.take(NR * d.ld_nC);
         e.DLOG = b.take(NR * d.ld_nA);
@@ -488,6 +509,9 @@ struct Ctx {
     size_t defer_small = 0;    // ... or only those of at most this many bytes (they stay in the L2)
     bool defer_this(size_t slab_bytes) const { return defer_slabs || (defer_small && slab_bytes <= defer_small); }
 
+    const char* wp3k(int i) const { return reinterpret_cast<const char*>(W + w.wp3k[i]); }
+    const char* wt3k(int i) const { return reinterpret_cast<const char*>(W + w.wt3k[i]); }
+    char* img(size_t off) const { return reinterpret_cast<char*>(E + off); }
     const float* wp(int i) const { return W + w.wp[i]; }
     const float* wt(int i) const { return W + w.wt[i]; }
     float* gp(int i) const { return W + w.gp[i]; }
@@ -1018,7 +1042,20 @@ static int pack_weights(const Dims& d, const WLayout& w, const float* const* par
         sb.d[sb.count++] = SplitDesc{W + w.wp[i], W + w.wp3[i], m.n, m.k, w.ldp[i], (m.k + 31) / 32};
         sb.d[sb.count++] = SplitDesc{W + w.wt[i], W + w.wt3[i], m.k, m.n, w.ldt[i], (m.n + 31) / 32};
     }
-    return launch_split_weights(sb, st);
+    MARL_TRY(launch_split_weights(sb, st));
+    ImgBatch ib{};
+    ib.count = 0;
+    for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const ParamMeta m = param_meta(d, i);
+        if (m.kind != PK_MATRIX || !w.wp3k[i]) continue;
+        if (ib.count + 2 > kMaxImgDesc) {
+            MARL_TRY(launch_images(ib, st));
+            ib.count = 0;
+        }
+        ib.d[ib.count++] = ImgDesc{W + w.wp[i], W + w.wp3k[i], m.n, m.k, w.ldp[i]};
+        ib.d[ib.count++] = ImgDesc{W + w.wt[i], W + w.wt3k[i], m.k, m.n, w.ldt[i]};
+    }
+    return launch_images(ib, st);
 }
 
 // tells the bf16x6 launchers where the image of each fp32 weight copy lives
@@ -1094,6 +1131,21 @@ static int ln_bwd_rank(const Ctx& c, const float* g, int ldg, int kin, int w1, c
     MARL_TRY(launch_ln_silu_bwd_rank(g, ldg, kin, c.wt(w1), p4(kin), z, ldz, stats, c.wp(pw),
                                      c.wp(pb), dz, lddz, part, rows, n, c.st));
     return launch_reduce_affine(part, ln_bwd_blocks(rows, n), n, grads[pw], grads[pb], 0, c.st, q);
+}
+
+// the panel launch could not write a gate-gradient image it was asked for (shapes without the row-wise
+// tail): build it from the fp32 gradients - correct, one extra pass
+static int gate_image_fallback(const Ctx& c, const PanelBwdProb& pd, int t) {
+    const Dims& d = c.d;
+    ImgBatch ib{};
+    ib.count = 0;
+    if (pd.has_cellb && pd.cellb.g3 && !pd.cellb_img_done)
+        ib.d[ib.count++] = ImgDesc{c.at(c.e.GB, t), c.img(c.e.GB3) + img_off((int64_t)t * d.R, 0, img_steps(4 * d.n_b)),
+                                   d.R, 4 * d.n_b, d.ld_gb};
+    if (pd.has_cell && pd.cell.g3 && !pd.cell_img_done)
+        ib.d[ib.count++] = ImgDesc{c.at(c.e.GA, t), c.img(c.e.GA3) + img_off((int64_t)t * d.R, 0, img_steps(4 * d.n_a)),
+                                   d.R, 4 * d.n_a, d.ld_ga};
+    return launch_images(ib, c.st);
 }
 
 static int episode_backward(const Ctx& c0, const void* img, int img_u8, const float* g_preds,
@@ -1192,20 +1244,24 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     bool action_done = false;  // the action cell of this step was handled by the ride-along
     bool belief_done = false;  // the belief cell: by the epilogue of the chained panel launch
     const bool chain = ride && use_chain(d);
+    const bool g3 = c.e.g3;  // the gate gradients also leave as k16 images; the products below read those
     const int pln_blocks = chain ? panel_chain_blocks(d.na, d.nb) : panel_bwd_blocks(R);
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
-        if (action_done && belief_done) {
-            // both cells of this step were handled inside the previous iteration's panel launch
-        } else if (action_done)
-            MARL_TRY(launch_lstm_cell_bwd(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb, c.at(c.e.GB, t),
-                                          d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb, d.R, d.n_b, st));
-        else
-            MARL_TRY(launch_lstm_cell_bwd2(c.DHs(t + 1), d.ld_nb, c.at(c.e.DC), d.ld_nb,
-                                           c.at(c.e.GB, t), d.ld_gb, c.Cs(t), c.Cs(t + 1), d.ld_nb,
-                                           d.n_b, c.DHCs(t + 1), d.ld_na, c.at(c.e.DCC), d.ld_na,
-                                           c.at(c.e.GA, t), d.ld_ga, c.CCs(t), c.CCs(t + 1),
-                                           d.ld_na, d.n_a, d.R, st));
+        {   // cells of step t not yet handled inside the previous iteration's panel launch
+            LstmBwdBatch lb{};
+            int nc = 0;
+            if (!belief_done)
+                lb.a[nc++] = LstmBwdArgs{c.DHs(t + 1), c.at(c.e.DC), c.at(c.e.GB, t), c.Cs(t), c.Cs(t + 1), d.ld_nb,
+                                         d.ld_nb, d.ld_gb, d.ld_nb, d.n_b, g3 ? c.img(c.e.GB3) : nullptr,
+                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_b)};
+            if (!action_done)
+                lb.a[nc++] = LstmBwdArgs{c.DHCs(t + 1), c.at(c.e.DCC), c.at(c.e.GA, t), c.CCs(t), c.CCs(t + 1), d.ld_na,
+                                         d.ld_na, d.ld_ga, d.ld_na, d.n_a, g3 ? c.img(c.e.GA3) : nullptr,
+                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_a)};
+            lb.rows = d.R;
+            if (nc) MARL_TRY(launch_lstm_cell_bwd_batch(lb, nc, st));
+        }
         action_done = belief_done = false;
         // The W_hh recurrent GEMM (main stream) and the decoder / encoder backward chain (side
         // stream) only meet at DH[t]: the chain's last kernel waits for the GEMM.
@@ -1249,7 +1305,22 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                                     c.wt(MARL_P_LA_WIH) + (size_t)d.nf * d.ld_ga, d.ld_ga, 4 * d.n_a,
                                     c.at(c.e.DDBAR2) + (size_t)t * s_nmo, d.ld_dbl, R, d.n_mo + d.n_d);
                 gb.count = 4;
-                MARL_TRY(launch_gemm_nt(gb, c.st));
+                if (g3) {
+                    const int r0 = (int)((int64_t)t * d.R);
+                    G3Batch g{};
+                    g.p[0] = g3_prob(c.img(c.e.GB3), r0, c.wt3k(MARL_P_LB_WHH), 0, 4 * d.n_b, c.DHs(t), d.ld_nb, R,
+                                     d.n_b, nullptr, 1);
+                    g.p[1] = g3_prob(c.img(c.e.GA3), r0, c.wt3k(MARL_P_LA_WHH), 0, 4 * d.n_a, c.DHCs(t), d.ld_na, R,
+                                     d.n_a, nullptr, 1);
+                    g.p[2] = g3_prob(c.img(c.e.GB3), r0, c.wt3k(MARL_P_LB_WIH), d.nf, 4 * d.n_b, ddbar, d.ld_dbl, R,
+                                     d.n_mo + d.n_d);
+                    g.p[3] = g3_prob(c.img(c.e.GA3), r0, c.wt3k(MARL_P_LA_WIH), d.nf, 4 * d.n_a,
+                                     c.at(c.e.DDBAR2) + (size_t)t * s_nmo, d.ld_dbl, R, d.n_mo + d.n_d);
+                    g.count = 4;
+                    MARL_TRY(launch_gemm_nt3(g, c.st));
+                } else {
+                    MARL_TRY(launch_gemm_nt(gb, c.st));
+                }
             } else {
                 gb.p[2] = p;
                 gb.count = 3;
@@ -1282,7 +1353,8 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
             if (ride && t > 0) {  // action cell of step t-1: gates GA[t-1], dh^ = DHC[t]
                 pd.has_cell = 1;
                 pd.cell = LstmBwdArgs{c.DHCs(t), c.at(c.e.DCC), c.at(c.e.GA, t - 1), c.CCs(t - 1),
-                                      c.CCs(t), d.ld_na, d.ld_na, d.ld_ga, d.ld_na, d.n_a};
+                                      c.CCs(t), d.ld_na, d.ld_na, d.ld_ga, d.ld_na, d.n_a,
+                                      g3 ? c.img(c.e.GA3) : nullptr, (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_a)};
                 pd.cell_rows = d.R;
                 action_done = true;
             }
@@ -1309,13 +1381,16 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                     pd.accumulate = 1;
                     pd.has_cellb = 1;
                     pd.cellb = LstmBwdArgs{c.DHs(t), c.at(c.e.DC), c.at(c.e.GB, t - 1), c.Cs(t - 1), c.Cs(t),
-                                           d.ld_nb, d.ld_nb, d.ld_gb, d.ld_nb, d.n_b};
+                                           d.ld_nb, d.ld_nb, d.ld_gb, d.ld_nb, d.n_b, g3 ? c.img(c.e.GB3) : nullptr,
+                                           (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_b)};
                     belief_done = true;
                 }
                 MARL_TRY(launch_panel_bwd(pd, st));
+                MARL_TRY(gate_image_fallback(c, pd, t - 1));
                 continue;
             }
             MARL_TRY(launch_panel_bwd(pd, st));
+            MARL_TRY(gate_image_fallback(c, pd, t - 1));
             if (t > 0) {
                 float* dze2 = c.at(c.e.DZE2) + (size_t)(t - 1) * s_nm;
                 float* dae1 = c.at(c.e.DAE1) + (size_t)(t - 1) * s_nm2;
@@ -1406,10 +1481,19 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     // ---- dU for all steps, then position embedding and CNN backward -------------------
     {
         // with the [nf, nin) columns already produced step by step, only the CNN features remain
+        if (g3 && dl_in_loop) {
+            G3Batch g{};
+            g.p[0] = g3_prob(c.img(c.e.GB3), 0, c.wt3k(MARL_P_LB_WIH), 0, 4 * d.n_b, c.at(c.e.DU), d.ld_nin, (int)NR,
+                             d.nf);
+            g3_add_seg(g.p[0], c.img(c.e.GA3), 0, c.wt3k(MARL_P_LA_WIH), 0, 4 * d.n_a);
+            g.count = 1;
+            MARL_TRY(launch_gemm_nt3(g, st));
+        } else {
         GemmProb p = gemm_prob(c.at(c.e.GB, 0), d.ld_gb, c.wt(MARL_P_LB_WIH), d.ld_gb, 4 * d.n_b,
                                c.at(c.e.DU), d.ld_nin, (int)NR, dl_in_loop ? d.nf : d.nin);
         gemm_add_seg(p, c.at(c.e.GA, 0), d.ld_ga, c.wt(MARL_P_LA_WIH), d.ld_ga, 4 * d.n_a);
         MARL_TRY(gemm1(c, p));
+        }
         if (dl_in_loop)  // d(position embedding) = belief share + action share
             MARL_TRY(launch_add2d(c.at(c.e.DDBAR) + d.n_mo, d.ld_dbl, c.at(c.e.DDBAR2) + d.n_mo, d.ld_dbl,
                                   c.at(c.e.DU) + d.nf + d.n_mo, d.ld_nin, NR, d.n_d, st));

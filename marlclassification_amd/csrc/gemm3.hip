@@ -1,0 +1,972 @@
+// Image GEMMs ("g3"): fp32-accurate products whose operands are BOTH pre-split in HBM.
+//
+// gemm_split.hip splits fp32 operands into three bf16 terms while it stages them - 5-6 VALU
+// instructions per MFMA, 48 staging registers, one LDS stage, two barriers per K tile: the 128 x 128
+// two-barrier structure tops out near 1/3 of the bf16 matrix pipe (MI355X guide, "step-3 ceiling").
+// Here the PRODUCER of every operand writes its k16 image (split.h: [row][k/16][plane][16] bf16,
+// 6 bytes per element) and the product kernel is a pure bf16 kernel:
+//   * tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane), no staging registers,
+//     no VALU; the LDS stage is the image itself (96-byte rows; a (32-row block, K step) chunk is 3 KB
+//     contiguous in memory = three whole instructions), the 16-byte piece index XOR-ed with bit 3 of
+//     the row on the SOURCE address and on the fragment read (conflict-free ds_read_b128,
+//     tools/lds_conflicts.py model);
+//   * a ring of NST stages of one 16-deep K step each, ONE barrier per step, counted vmcnt: NST - 2
+//     steps stay in flight across every barrier;
+//   * the fragments of step s + 1 are read (other register set) while the 6 x TM x TN MFMAs of step
+//     s issue - the matrix pipe only drains at the barrier itself;
+//   * six products per fp32 product, smallest terms first, fp32 accumulation (gemm_split.hip).
+// The LSTM form fuses the cell update in the epilogue like gemm_nt_split_kernel<.., LSTM> and ALSO
+// writes the image of h' (through an LDS transposition, 96 contiguous bytes per lane), which is
+// the A operand of the next step's launch and of the batched heads.
+#include <stdlib.h>
+
+#include "common.h"
+#include "split.h"
+
+namespace marl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_acc(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+}  // namespace
+
+// BM x BN tile, WM x WN waves (wave tile (BM / WM) x (BN / WN) in 32 x 32 blocks), NST ring stages.
+// LSTM: BN = 4 gates x 32 units, WN = 1 (a lane holds the four gates of its (row, unit) elements).
+template <int BM, int BN, int WM, int WN, int NST, bool LSTM, int ABL>
+__global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch batch) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the stub: the buffer-resource type is device-only)
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * kImgRowBytes, B_BYTES = BN * kImgRowBytes, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INS = A_BYTES / 1024, B_INS = B_BYTES / 1024;  // wave-instructions per step
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "whole LDS-DMA instructions");
+    // the A_INS + B_INS instructions of a step are dealt round robin: wave w issues t = w + NW i
+    constexpr int T_INS = A_INS + B_INS, NI_LO = T_INS / NW, NI_HI = (T_INS + NW - 1) / NW;
+    constexpr int I_EXTRA = T_INS % NW;  // waves [0, I_EXTRA) issue NI_HI instructions
+    static_assert(!LSTM || (BN == 128 && WN == 1), "LSTM tile = 4 gates x 32 units per wave");
+
+    // ABL (perf diagnosis only): 0 product build, 1 every step fully waited for (SAFE), 2 no LDS-DMA in
+    // the loop, 3 no MFMA, 4 block-major source addresses (1 KB contiguous per instruction; wrong data),
+    // 5 no fragment reads in the loop
+    constexpr bool SAFE = ABL == 1;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (batch.xcd_map) xcd_tile(batch.gx, batch.gy, batch.count, bx, by, bz);
+    const G3Prob& P = batch.p[bz];
+    const int M = P.m;
+    const int N = P.n;  // LSTM: hidden units (B has 4 N rows)
+    const int n0 = by * (LSTM ? 32 : BN);
+    const int m0 = bx * BM;
+    if (m0 >= M || n0 >= N) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MARL_G3_ABLATE
+    const bool probe = batch.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+    if (probe) {
+        batch.clk[0] = __builtin_readcyclecounter();
+        batch.clk[1] = wall_clock64();
+    }
+#endif
+    const int wm = wave / WN, wn = wave % WN;
+    const bool extra_i = wave < I_EXTRA;
+    const int S0 = P.seg[0].steps, S = S0 + (P.nseg > 1 ? P.seg[1].steps : 0);
+
+    // ---- LDS-DMA source offsets of this lane: instruction j covers pieces q = 64 j + lane of the
+    // stage image, piece q = (row q / 6, plane (q % 6) / 2, 16-byte half (q % 6) % 2)
+    int voff[NI_HI];
+    __amdgpu_buffer_rsrc_t rA, rB;
+    auto set_seg = [&](int sg) {
+        const G3Seg& g = P.seg[sg];
+        const int blk = g.steps * kImgChunkBytes;  // bytes from one row block to the next
+        // A: offsets relative to the tile's first row block (64-bit base), B: to the image start
+        const int64_t a_first = (int64_t)g.a_row0 + m0;
+        const int a_blk0 = (int)(a_first >> 5);
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) {
+            const int t = wave + NW * i;
+            const bool isA = t < A_INS;
+            const int q = (isA ? t : t - A_INS) * 64 + lane;
+            int row = q / 6;
+            const int w = q - row * 6;
+            const int sw = (row >> 3) & 1;
+            int grow;
+            if (isA) {
+                row = m0 + row < M ? row : M - 1 - m0;
+                grow = (int)(a_first + row - ((int64_t)a_blk0 << 5));
+            } else if (LSTM) {
+                int unit = n0 + (row & 31);
+                unit = unit < N ? unit : N - 1;
+                grow = g.b_row0 + (row >> 5) * N + unit;
+            } else {
+                grow = n0 + row;
+                grow = g.b_row0 + (grow < N ? grow : N - 1);
+            }
+            voff[i] = (grow >> 5) * blk + (grow & 31) * kImgRowBytes + (w >> 1) * 32 + (((w & 1) ^ sw) << 4);
+        }
+        rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.a3) + (size_t)a_blk0 * blk, 0, 0x7fffffff, 0x00020000);
+        rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.b3), 0, 0x7fffffff, 0x00020000);
+    };
+    int gi = 0, islot = 0;  // next step to issue and its ring slot
+    auto issue = [&]() {
+        if (gi == S0) set_seg(1);
+        const int soff = (gi >= S0 ? gi - S0 : gi) * kImgChunkBytes;
+        char* base = sm + islot * ST_BYTES;
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) {
+            const int t = wave + NW * i;
+            if (i == NI_LO && !extra_i) break;  // (NI_LO < NI_HI: only the first I_EXTRA waves)
+            if (t < A_INS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(base + t * 1024), 16, voff[i], soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(base + t * 1024), 16, voff[i], soff, 0, 0);
+        }
+        ++gi;
+        islot = islot + 1 == NST ? 0 : islot + 1;
+    };
+
+    // fragment addresses: row = wave tile row + lane % 32, 16-byte half (lane / 32) ^ bit 3 of the row
+    const int fsw = ((lane >> 5) ^ ((lane >> 3) & 1)) << 4;
+    const char* lA = sm + (wm * (BM / WM) + (lane & 31)) * kImgRowBytes + fsw;
+    const char* lB = sm + A_BYTES + (wn * (BN / WN) + (lane & 31)) * kImgRowBytes + fsw;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NF = 3 * (TM + TN), NMMA = 6 * TM * TN;  // fragment reads / MFMAs of one step
+    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+#define G3_LOADF(fa_, fb_, slot_)                                                           \
+    {                                                                                       \
+        const char* pa_ = lA + (slot_) * ST_BYTES;                                          \
+        const char* pb_ = lB + (slot_) * ST_BYTES;                                          \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                     \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                  \
+                fa_[p][i] = *reinterpret_cast<const bf16x8*>(pa_ + i * 32 * kImgRowBytes + p * 32); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                  \
+                fb_[p][j] = *reinterpret_cast<const bf16x8*>(pb_ + j * 32 * kImgRowBytes + p * 32); \
+        }                                                                                   \
+    }
+#define G3_P(fa_, fb_, pa_, pb_)                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[pa_][i], fb_[pb_][j], acc[i][j], 0, 0, 0);
+#define G3_MMA(fa_, fb_)                                                                    \
+    G3_P(fa_, fb_, 1, 1) G3_P(fa_, fb_, 0, 2) G3_P(fa_, fb_, 2, 0)                          \
+    G3_P(fa_, fb_, 0, 1) G3_P(fa_, fb_, 1, 0) G3_P(fa_, fb_, 0, 0)
+    // one K step; `cur` holds (is receiving) the fragments of step s.  MAIN: a step is left to issue and
+    // NST - 2 steps stay in flight across the barrier; else (the last NST steps) everything is waited for.
+#define G3_WAIT(k_)                                                                         \
+    if (I_EXTRA > 0 && extra_i) wait_vm<(k_) * NI_HI>(); else wait_vm<(k_) * NI_LO>();
+#define G3_BODY(fa_, fb_, fan_, fbn_, MAIN_)                                                \
+    {                                                                                       \
+        if (MAIN_ && !SAFE) { G3_WAIT(NST - 2) } else wait_vm<0>();                         \
+        __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): my reads of step s are done */   \
+        __builtin_amdgcn_s_barrier();                                                       \
+        if (ABL == 2) { if (gi < S) ++gi; } else if (MAIN_ || gi < S) issue();              \
+        rslot = rslot + 1 == NST ? 0 : rslot + 1;                                           \
+        if (ABL != 5 && (MAIN_ || s + 1 < S)) G3_LOADF(fan_, fbn_, rslot)                   \
+        if (ABL != 3 && ABL != 6) { G3_MMA(fa_, fb_) } else { G3_KEEP(fa_, fb_) }                       \
+        if (MAIN_ && ABL != 3 && ABL != 5 && ABL != 6) { /* next step's fragment reads between the FIRST MFMAs */ \
+            _Pragma("unroll") for (int q = 0; q < (NF + 1) / 2; ++q) {                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                          \
+            }                                                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA - (NF + 1) / 2, 0);            \
+        }                                                                                   \
+        ++s;                                                                                \
+    }
+#define G3_KEEP(fa_, fb_)                                                                   \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                         \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa_[p][i]));   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb_[p][j]));   \
+    }
+
+    set_seg(0);
+#pragma unroll
+    for (int g = 0; g < NST; ++g)
+        if (g < S) issue();
+    if (!SAFE && S >= NST) { G3_WAIT(NST - 1) } else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    int s = 0, rslot = 0;
+    G3_LOADF(fa0, fb0, 0)
+    while (gi + 1 < S) {  // two steps per trip: both have a step to issue
+        G3_BODY(fa0, fb0, fa1, fb1, true)
+        G3_BODY(fa1, fb1, fa0, fb0, true)
+    }
+    while (s + 1 < S) {
+        G3_BODY(fa0, fb0, fa1, fb1, false)
+        G3_BODY(fa1, fb1, fa0, fb0, false)
+    }
+    if (s < S) G3_BODY(fa0, fb0, fa1, fb1, false)
+#undef G3_BODY
+#undef G3_KEEP
+#undef G3_WAIT
+#undef G3_MMA
+#undef G3_P
+#undef G3_LOADF
+
+    // ---- epilogue.  acc[i][j][r] is C[row(r), col], col = lane & 31, row(r) = (r & 3) + 8 * (r >> 2) +
+    // 4 * (lane >> 5): one column and 16 rows per lane, i.e. 4-byte stores - and a store costs its ISSUE
+    // slot (~70 cycles per wave-instruction and CU), not its bytes (MI355X guide, T21).  Every 32 x 32
+    // block therefore goes through a wave-private LDS panel and leaves as FOUR 16-byte stores per lane
+    // (8 rows x 128 contiguous bytes per instruction) instead of sixteen 4-byte ones.
+    constexpr int HLD = 36;  // floats per panel row (16-byte aligned rows, conflict-free enough)
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    float* hp = reinterpret_cast<float*>(sm) + wave * 32 * HLD;
+    const int tr = lane >> 3, tc = (lane & 7) * 4;  // read-back: rows tr + 8 q, columns tc .. tc + 3
+    __syncthreads();  // every wave is done with the ring before the panels overwrite it
+#define G3_PANEL_PUT(val_)                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                          \
+        hp[((r & 3) + 8 * (r >> 2) + row_h) * HLD + col_l] = (val_);
+#define G3_PANEL_GET(q_) (*reinterpret_cast<const float4*>(hp + (tr + 8 * (q_)) * HLD + tc))
+    if (!LSTM) {
+        const bool vec = (P.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(P.c) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cb = n0 + wn * (BN / WN) + j * 32;  // first column of the block
+                if (cb >= N) continue;
+                const int rb = m0 + wm * (BM / WM) + i * 32;
+                G3_PANEL_PUT(acc[i][j][r])
+                wait_lgkm0();
+                const int col = cb + tc;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P.bias) {
+                    bv.x = col < N ? P.bias[col] : 0.f;
+                    bv.y = col + 1 < N ? P.bias[col + 1] : 0.f;
+                    bv.z = col + 2 < N ? P.bias[col + 2] : 0.f;
+                    bv.w = col + 3 < N ? P.bias[col + 3] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rb + tr + 8 * q;
+                    float4 v = G3_PANEL_GET(q);
+                    v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    if (row >= M || col >= N) continue;
+                    float* cp = P.c + (size_t)row * P.ldc + col;
+                    if (vec && col + 3 < N) {
+                        if (P.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(cp);
+                            v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(cp) = v;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (col + u < N) cp[u] = P.accumulate ? cp[u] + e[u] : e[u];
+                    }
+                }
+                wait_lgkm0();  // (the panel is rewritten by the next block)
+            }
+    } else {
+        // (TM == 1, TN == 4: acc[0][g] = gate g of unit n0 + col_l, 16 rows of the wave's 32)
+        const int unit = n0 + col_l;
+        const bool uok = unit < N;
+        const int uc = uok ? unit : N - 1;
+        const float bi = P.bias[uc], bf = P.bias[N + uc], bg = P.bias[2 * N + uc], bo = P.bias[3 * N + uc];
+        const int rb = m0 + wm * 32;
+        float cprev[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row_ = rb + (r & 3) + 8 * (r >> 2) + row_h;
+            row_ = row_ < M ? row_ : M - 1;
+            cprev[r] = P.c_prev[(size_t)row_ * P.ld_state + uc];
+        }
+        // activated gates in place of the pre-activations, then c' and h' (zeros past the last unit: the
+        // padding columns of the state buffers and of the image stay zero)
+        float cn[16], hn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float gi_ = sigmoid_acc(acc[0][0][r] + bi);
+            const float gf = sigmoid_acc(acc[0][LSTM ? 1 : 0][r] + bf);
+            const float gg = tanh_fast(acc[0][LSTM ? 2 : 0][r] + bg);
+            const float go = sigmoid_acc(acc[0][LSTM ? 3 : 0][r] + bo);
+            acc[0][0][r] = gi_;
+            acc[0][LSTM ? 1 : 0][r] = gf;
+            acc[0][LSTM ? 2 : 0][r] = gg;
+            acc[0][LSTM ? 3 : 0][r] = go;
+            const float c_ = gf * cprev[r] + gi_ * gg;
+            cn[r] = uok ? c_ : 0.f;
+            hn[r] = uok ? go * tanh_fast(c_) : 0.f;
+        }
+        const int col = n0 + tc;
+        const bool col_ok = col < ((N + 3) & ~3);  // state rows are pad4(N) wide (zeros behind N)
+        // one [32 rows][32 units] block -> dst[row * ld + col0 + unit]; vec: 16-byte stores allowed
+#define G3_PANEL_STORE(dst_, ld_, col0_, vec_)                                              \
+        {                                                                                   \
+            wait_lgkm0();                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                 \
+                const int row = rb + tr + 8 * q;                                            \
+                const float4 v = G3_PANEL_GET(q);                                           \
+                if (row >= M) continue;                                                     \
+                float* cp = (dst_) + (size_t)row * (ld_) + (col0_) + col;                   \
+                if (vec_) {                                                                 \
+                    if (col_ok) *reinterpret_cast<float4*>(cp) = v;                         \
+                } else {                                                                    \
+                    if (col < N) cp[0] = v.x;                                               \
+                    if (col + 1 < N) cp[1] = v.y;                                           \
+                    if (col + 2 < N) cp[2] = v.z;                                           \
+                    if (col + 3 < N) cp[3] = v.w;                                           \
+                }                                                                           \
+            }                                                                               \
+            wait_lgkm0();                                                                   \
+        }
+        const bool svec = (P.ld_state & 3) == 0;
+        G3_PANEL_PUT(cn[r])
+        G3_PANEL_STORE(P.c_next, P.ld_state, 0, svec)
+        if (P.gates) {
+            const bool gvec = (N & 3) == 0 && (P.ld_gates & 3) == 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                G3_PANEL_PUT(acc[0][LSTM ? g : 0][r])
+                G3_PANEL_STORE(P.gates, P.ld_gates, g * N, gvec)
+            }
+        }
+        G3_PANEL_PUT(hn[r])
+        G3_PANEL_STORE(P.h_next, P.ld_state, 0, svec)
+        if (P.h3) {
+            // (the h' panel is still in LDS) lane = (row lane / 2, 16 units (lane & 1) * 16 ..) = one image
+            // step of that row: 96 contiguous bytes
+            const int lr = lane >> 1, u0 = (lane & 1) * 16;
+            const int row = rb + lr;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(hp + lr * HLD + u0 + 4 * q);
+                v[4 * q] = t.x;
+                v[4 * q + 1] = t.y;
+                v[4 * q + 2] = t.z;
+                v[4 * q + 3] = t.w;
+            }
+            if (row < M && n0 + u0 < ((N + 15) & ~15))
+                img_store16(P.h3 + img_off((int64_t)P.h3_row0 + row, (n0 + u0) >> 4, P.h3_steps), v);
+        }
+#undef G3_PANEL_STORE
+    }
+#undef G3_PANEL_PUT
+#undef G3_PANEL_GET
+#ifdef MARL_G3_ABLATE
+    if (probe) {
+        batch.clk[2] = __builtin_readcyclecounter();
+        batch.clk[3] = wall_clock64();
+    }
+#endif
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// TN: C[NI,NJ] = sum_r A[r,i] * B[r,j] over the row slab of this workgroup (weight gradients), both
+// operands k16 images whose ROWS are the contraction index.  A stage = 16 rows x (BI + BJ) columns:
+// per 16-column step of an operand 1536 contiguous bytes (half a row block), so the LDS stage is
+// [column step][16 row slots][3 planes][16 columns] and the MFMA fragments (8 consecutive ROWS of one
+// column per lane) come out of it with the transposing read ds_read_b64_tr_b16: lanes 4q..4q+3 of a
+// 16-lane group supply row q of a [4 rows][16 columns] block, lane j receives column j.  Row slot s of
+// an ODD column step holds row s ^ 4 (on the DMA source address and on the read): the two 16-lane
+// groups of a read then hit disjoint banks.  Same ring / barrier / MFMA structure as the NT kernel.
+// csum (nullable, column tile 0 only): column sums of A from three more MFMAs per row block against a
+// fragment of ones.
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+
+template <int BI, int BJ, int WI, int WJ, int NST>
+__global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WI * WJ;
+    constexpr int TM = BI / WI / 32, TN = BJ / WJ / 32;
+    constexpr int CS_BYTES = 16 * kImgRowBytes;  // one column step of a stage: 16 rows x 96 bytes
+    constexpr int A_BYTES = (BI / 16) * CS_BYTES, B_BYTES = (BJ / 16) * CS_BYTES, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INS = A_BYTES / 1024, B_INS = B_BYTES / 1024;
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "whole LDS-DMA instructions");
+    constexpr int T_INS = A_INS + B_INS, NI_LO = T_INS / NW, NI_HI = (T_INS + NW - 1) / NW;
+    constexpr int I_EXTRA = T_INS % NW;
+    constexpr int NF = 6 * (TM + TN), NMMA = 6 * TM * TN;
+
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (P.gx > 0) xcd_tile(P.gx, P.gy, P.gz, bx, by, bz);
+    const int i0 = bx * BI, j0 = by * BJ;
+    const int64_t r_begin = (int64_t)bz * P.rows_per_split;
+    int64_t r_end = r_begin + P.rows_per_split;
+    if (r_end > P.rows) r_end = P.rows;
+    const int S = r_end > r_begin ? (int)((r_end - r_begin) >> 4) : 0;  // stages of 16 rows
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WJ, wn = wave % WJ;
+    const bool extra_i = wave < I_EXTRA;
+
+    // LDS-DMA source offsets: instruction t covers pieces q = 64 t' + lane of its operand's stage,
+    // piece q = (column step q / 96, row slot (q % 96) / 6, 16-byte piece (q % 96) % 6)
+    int voff[NI_HI];
+#pragma unroll
+    for (int i = 0; i < NI_HI; ++i) {
+        const int t = wave + NW * i;
+        const bool isA = t < A_INS;
+        const int q = (isA ? t : t - A_INS) * 64 + lane;
+        const int csl = q / 96, w = q - csl * 96, slot = w / 6, pw = w - slot * 6;
+        const int steps = isA ? P.a_steps : P.b_steps;
+        int cs = (isA ? i0 : j0) / 16 + csl;
+        cs = cs < steps ? cs : steps - 1;  // (columns past the operand's width: never stored)
+        voff[i] = cs * kImgChunkBytes + (slot ^ ((csl & 1) << 2)) * kImgRowBytes + pw * 16;
+    }
+    const int a_blk = P.a_steps * kImgChunkBytes, b_blk = P.b_steps * kImgChunkBytes;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(P.a3) + (size_t)((P.a_row0 + r_begin) >> 5) * a_blk, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(P.b3) + (size_t)((P.b_row0 + r_begin) >> 5) * b_blk, 0, 0x7fffffff, 0x00020000);
+    int gi = 0, islot = 0;
+    auto issue = [&]() {
+        const int half = (gi & 1) * CS_BYTES;  // rows 0..15 / 16..31 of the row block gi / 2
+        const int soffA = (gi >> 1) * a_blk + half, soffB = (gi >> 1) * b_blk + half;
+        char* base = sm + islot * ST_BYTES;
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) {
+            const int t = wave + NW * i;
+            if (i == NI_LO && !extra_i) break;
+            if (t < A_INS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(base + t * 1024), 16, voff[i], soffA, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(base + t * 1024), 16, voff[i], soffB, 0, 0);
+        }
+        ++gi;
+        islot = islot + 1 == NST ? 0 : islot + 1;
+    };
+
+    // fragment addresses (see the header): 16-lane group g = lane / 16 -> column sub-step g & 1, row
+    // group g / 2; lane j = 4 q + piece; the two reads of a fragment take rows 4 h + q, h = 0, 1
+    const int g16 = lane >> 4, sub = g16 & 1, kg = g16 >> 1, qrow = (lane >> 2) & 3, piece = lane & 3;
+    const int f0 = sub * CS_BYTES + (8 * kg + 4 * sub + qrow) * kImgRowBytes + piece * 8;        // h = 0
+    const int f1 = sub * CS_BYTES + (8 * kg + 4 * (1 - sub) + qrow) * kImgRowBytes + piece * 8;  // h = 1
+    const char* lA0 = sm + wm * (BI / WI / 16) * CS_BYTES + f0;
+    const char* lA1 = sm + wm * (BI / WI / 16) * CS_BYTES + f1;
+    const char* lB0 = sm + A_BYTES + wn * (BJ / WJ / 16) * CS_BYTES + f0;
+    const char* lB1 = sm + A_BYTES + wn * (BJ / WJ / 16) * CS_BYTES + f1;
+
+    f32x16 acc[TM][TN], accs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const bool do_csum = P.csum != nullptr && by == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;  // bf16 1.0
+
+    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+#define G3T_FRAG(p0_, p1_, off_)                                                                     \
+    __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p0_) + (off_))),    \
+                            __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p1_) + (off_))), 0, 1, 2, 3, 4, 5, 6, 7)
+#define G3T_LOADF(fa_, fb_, slot_)                                                                   \
+    {                                                                                                \
+        const int so_ = (slot_) * ST_BYTES;                                                          \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                              \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+                fa_[p][i] = G3T_FRAG(lA0, lA1, so_ + i * 2 * CS_BYTES + p * 32);                     \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+                fb_[p][j] = G3T_FRAG(lB0, lB1, so_ + j * 2 * CS_BYTES + p * 32);                     \
+        }                                                                                            \
+    }
+#define G3T_P(fa_, fb_, pa_, pb_)                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[pa_][i], fb_[pb_][j], acc[i][j], 0, 0, 0);
+#define G3T_MMA(fa_, fb_)                                                                            \
+    G3T_P(fa_, fb_, 1, 1) G3T_P(fa_, fb_, 0, 2) G3T_P(fa_, fb_, 2, 0)                                \
+    G3T_P(fa_, fb_, 0, 1) G3T_P(fa_, fb_, 1, 0) G3T_P(fa_, fb_, 0, 0)                                \
+    if (do_csum) {                                                                                   \
+        _Pragma("unroll") for (int p = 2; p >= 0; --p)                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+                accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[p][i], ones, accs[i], 0, 0, 0); \
+    }
+#define G3T_WAIT(k_)                                                                                 \
+    if (I_EXTRA > 0 && extra_i) wait_vm<(k_) * NI_HI>(); else wait_vm<(k_) * NI_LO>();
+#define G3T_BODY(fa_, fb_, fan_, fbn_, MAIN_)                                                        \
+    {                                                                                                \
+        if (MAIN_ && !P.safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                               \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                          \
+        __builtin_amdgcn_s_barrier();                                                                \
+        if (MAIN_ || gi < S) issue();                                                                \
+        rslot = rslot + 1 == NST ? 0 : rslot + 1;                                                    \
+        if (MAIN_ || s + 1 < S) G3T_LOADF(fan_, fbn_, rslot)                                         \
+        G3T_MMA(fa_, fb_)                                                                            \
+        if (MAIN_) {                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < NF / 4; ++q) {                                     \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                   \
+            }                                                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, NMMA - NF / 4, 0);                           \
+        }                                                                                            \
+        ++s;                                                                                         \
+    }
+
+    if (S > 0) {
+#pragma unroll
+        for (int g = 0; g < NST; ++g)
+            if (g < S) issue();
+        if (!P.safe && S >= NST) { G3T_WAIT(NST - 1) } else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        int s = 0, rslot = 0;
+        G3T_LOADF(fa0, fb0, 0)
+        while (gi + 1 < S) {
+            G3T_BODY(fa0, fb0, fa1, fb1, true)
+            G3T_BODY(fa1, fb1, fa0, fb0, true)
+        }
+        while (s + 1 < S) {
+            G3T_BODY(fa0, fb0, fa1, fb1, false)
+            G3T_BODY(fa1, fb1, fa0, fb0, false)
+        }
+        if (s < S) G3T_BODY(fa0, fb0, fa1, fb1, false)
+    }
+#undef G3T_BODY
+#undef G3T_WAIT
+#undef G3T_MMA
+#undef G3T_P
+#undef G3T_LOADF
+#undef G3T_FRAG
+
+    // ---- epilogue: the slab of this split, through the wave-private LDS panels (16-byte stores)
+    constexpr int HLD = 36;
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    float* hp = reinterpret_cast<float*>(sm) + wave * 32 * HLD;
+    const int tr = lane >> 3, tc = (lane & 7) * 4;
+    __syncthreads();
+    float* o = P.out + (size_t)bz * P.out_split_stride;
+    const bool vec = (P.ldo & 3) == 0 && (P.out_split_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(P.out) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rb = i0 + wm * (BI / WI) + i * 32;
+        if (do_csum && wn == 0 && col_l == 0) {  // every column of accs[i] holds the same sums
+            float* co = P.csum + (size_t)bz * P.ni;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2) + row_h;
+                if (row < P.ni) co[row] = accs[i][r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = j0 + wn * (BJ / WJ) + j * 32;
+            if (cb >= P.nj || rb >= P.ni) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hp[((r & 3) + 8 * (r >> 2) + row_h) * HLD + col_l] = acc[i][j][r];
+            wait_lgkm0();
+            const int col = cb + tc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rb + tr + 8 * q;
+                const float4 v = *reinterpret_cast<const float4*>(hp + (tr + 8 * q) * HLD + tc);
+                if (row >= P.ni || col >= P.nj) continue;
+                float* cp = o + (size_t)row * P.ldo + col;
+                if (vec && col + 3 < P.nj) {
+                    *reinterpret_cast<float4*>(cp) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (col + u < P.nj) cp[u] = e[u];
+                }
+            }
+            wait_lgkm0();
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// fp32 matrix -> k16 image (weights after every optimiser step; operands of the kernel-level API)
+// ---------------------------------------------------------------------------
+__global__ void image_kernel(const ImgBatch B) {
+    const ImgDesc& d = B.d[blockIdx.y];
+    const int steps = (d.k + 15) >> 4;
+    const int64_t rows32 = (d.rows + 31) & ~(int64_t)31;
+    const int64_t tot = rows32 * steps * 2;  // one thread per 8 consecutive k
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / (steps * 2);
+        const int k0 = (int)(idx - r * steps * 2) * 8;
+        float v[8];
+        if (r >= d.rows) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        } else {
+            const float* s = d.src + r * d.ld + k0;
+            if (k0 + 8 <= d.k && (d.ld & 3) == 0) {
+                const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+                v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = k0 + q < d.k ? s[q] : 0.f;
+            }
+        }
+        img_store8(static_cast<char*>(d.dst) + img_off(r, k0 >> 4, steps), k0, v);
+    }
+}
+
+int launch_images(const ImgBatch& b, hipStream_t st) {
+    if (b.count <= 0) return MARL_OK;
+    if (b.count > kMaxImgDesc) return MARL_EINVAL;
+    int64_t mx = 0;
+    for (int i = 0; i < b.count; ++i) {
+        const int64_t t = ((b.d[i].rows + 31) & ~(int64_t)31) * img_steps(b.d[i].k) * 2;
+        mx = t > mx ? t : mx;
+    }
+    int64_t gx = cdiv(mx, 256);
+    gx = gx > 2048 ? 2048 : (gx < 1 ? 1 : gx);
+    hipLaunchKernelGGL(image_kernel, dim3((unsigned)gx, (unsigned)b.count), dim3(256), 0, st, b);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+G3Prob g3_prob(const void* a3, int a_row0, const void* b3, int b_row0, int k, float* c, int ldc, int m, int n,
+               const float* bias, int accumulate) {
+    G3Prob p{};
+    p.seg[0] = G3Seg{static_cast<const char*>(a3), static_cast<const char*>(b3), a_row0, b_row0, img_steps(k)};
+    p.nseg = 1;
+    p.m = m;
+    p.n = n;
+    p.c = c;
+    p.ldc = ldc;
+    p.bias = bias;
+    p.accumulate = accumulate;
+    return p;
+}
+void g3_add_seg(G3Prob& p, const void* a3, int a_row0, const void* b3, int b_row0, int k) {
+    p.seg[1] = G3Seg{static_cast<const char*>(a3), static_cast<const char*>(b3), a_row0, b_row0, img_steps(k)};
+    p.nseg = 2;
+}
+
+template <int BM, int BN, int WM, int WN, int NST, bool LSTM>
+static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st) {
+    dim3 grid((unsigned)cdiv(max_m, BM), (unsigned)cdiv(max_n, LSTM ? 32 : BN), (unsigned)batch.count);
+    batch.gx = (int)grid.x;
+    batch.gy = (int)grid.y;
+    batch.xcd_map = batch.count == 1 && !LSTM && tune_get("nt_xcd", 1);
+    if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
+    batch.safe = tune_get("g3_safe", 0);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
+    static_assert(lds <= 160 * 1024, "LDS ring");
+    static_assert((size_t)WM * WN * 32 * 36 * 4 <= lds, "epilogue panels fit the ring");
+    const int abl = batch.safe;
+#ifdef MARL_G3_ABLATE
+    static long long* d_clk = nullptr;
+    if (!d_clk) MARL_HIP_CHECK(hipMalloc(&d_clk, 4 * sizeof(long long)));
+    batch.clk = tune_get("g3_clk", 0) ? d_clk : nullptr;
+#endif
+#define G3_LAUNCH(ABL_)                                                                                   \
+    {                                                                                                     \
+        auto kern = gemm_nt3_kernel<BM, BN, WM, WN, NST, LSTM, ABL_>;                                     \
+        static bool raised = false;                                                                       \
+        if (lds > 64 * 1024 && !raised) {                                                                 \
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+            raised = true;                                                                                \
+        }                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, batch);                               \
+    }
+    if (abl == 0) G3_LAUNCH(0)
+    else if (abl == 1) G3_LAUNCH(1)
+#ifdef MARL_G3_ABLATE
+    else if (abl == 2) G3_LAUNCH(2)
+    else if (abl == 3) G3_LAUNCH(3)
+    else if (abl == 4) G3_LAUNCH(4)
+    else if (abl == 5) G3_LAUNCH(5)
+    else if (abl == 6) G3_LAUNCH(6)
+#endif
+    else return MARL_EINVAL;
+#undef G3_LAUNCH
+#ifdef MARL_G3_ABLATE
+    if (batch.clk) {
+        long long h[4];
+        MARL_HIP_CHECK(hipMemcpy(h, batch.clk, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[g3 clk] block 0: %.1f us, %.0f MHz shader clock\n", (h[3] - h[1]) * 0.01,
+                (double)(h[2] - h[0]) / ((h[3] - h[1]) * 0.01));
+    }
+#endif
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+static int check_g3(const G3Prob& p, bool lstm) {
+    if (p.m <= 0 || p.n <= 0 || p.nseg < 1 || p.nseg > 2) {
+        set_error("g3: empty problem m=%d n=%d nseg=%d", p.m, p.n, p.nseg);
+        return MARL_EINVAL;
+    }
+    for (int s = 0; s < p.nseg; ++s) {
+        const G3Seg& g = p.seg[s];
+        if (!g.a3 || !g.b3 || g.steps <= 0 || g.a_row0 < 0 || g.b_row0 < 0 ||
+            (reinterpret_cast<uintptr_t>(g.a3) & 15) || (reinterpret_cast<uintptr_t>(g.b3) & 15)) {
+            set_error("g3: bad operand image (seg %d)", s);
+            return MARL_EINVAL;
+        }
+        // 32-bit byte offsets: within the row blocks of a tile for A, over all rows for B
+        const int64_t brows = g.b_row0 + (lstm ? 4 * (int64_t)p.n : (int64_t)p.n) + 32;
+        if ((brows >> 5) * g.steps * kImgChunkBytes >= (1ll << 31) || 10ll * g.steps * kImgChunkBytes >= (1ll << 31)) {
+            set_error("g3: operand image of seg %d too large for 32-bit offsets", s);
+            return MARL_ELIMIT;
+        }
+    }
+    return MARL_OK;
+}
+
+// variant: 0 = automatic, else (perf experiments) 1: 256 x 128 / 8 waves, 2: 128 x 128 / 4 waves,
+// 3: 128 x 64 / 4 waves
+int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
+    if (batch.count < 1 || batch.count > kMaxG3) return MARL_EINVAL;
+    int max_m = 0, max_n = 0;
+    int64_t blocks128 = 0;
+    for (int i = 0; i < batch.count; ++i) {
+        MARL_TRY(check_g3(batch.p[i], false));
+        if (!batch.p[i].c) return MARL_EINVAL;
+        max_m = batch.p[i].m > max_m ? batch.p[i].m : max_m;
+        max_n = batch.p[i].n > max_n ? batch.p[i].n : max_n;
+        blocks128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 128);
+    }
+    if (!variant) variant = tune_get("g3_nt_variant", 0);
+    if (!variant) variant = blocks128 >= 1024 && max_n >= 96 ? 1 : (blocks128 >= 384 && max_n >= 96 ? 2 : 3);
+    prof_before(1, st);
+    int rc;
+    if (variant == 1)
+        rc = launch_g3_variant<256, 128, 4, 2, 4, false>(batch, max_m, max_n, st);
+    else if (variant == 2)
+        rc = launch_g3_variant<128, 128, 2, 2, 3, false>(batch, max_m, max_n, st);
+#ifdef MARL_G3_ABLATE
+    else if (variant == 4)  // one workgroup per CU, six stages
+        rc = launch_g3_variant<128, 128, 2, 2, 6, false>(batch, max_m, max_n, st);
+    else if (variant == 5)  // eight waves on a 128 x 128 tile
+        rc = launch_g3_variant<128, 128, 4, 2, 3, false>(batch, max_m, max_n, st);
+    else if (variant == 6)  // eight waves, 256 x 128, three stages (2 workgroups would need 216 KB: still 1 per CU)
+        rc = launch_g3_variant<256, 128, 4, 2, 3, false>(batch, max_m, max_n, st);
+#endif
+    else
+        rc = launch_g3_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
+    prof_after(1, st);
+    return rc;
+}
+
+int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
+    if (batch.count < 1 || batch.count > kMaxG3) return MARL_EINVAL;
+    int max_m = 0, max_n = 0;
+    for (int i = 0; i < batch.count; ++i) {
+        const G3Prob& p = batch.p[i];
+        MARL_TRY(check_g3(p, true));
+        if (!p.bias || !p.c_prev || !p.h_next || !p.c_next) return MARL_EINVAL;
+        max_m = p.m > max_m ? p.m : max_m;
+        max_n = p.n > max_n ? p.n : max_n;
+    }
+    if (!variant) variant = tune_get("g3_lstm_variant", 0);
+    if (!variant) variant = 2;
+    prof_before(0, st);
+    int rc;
+    if (variant == 1)
+        rc = launch_g3_variant<256, 128, 8, 1, 4, true>(batch, max_m, max_n, st);
+    else
+        rc = launch_g3_variant<128, 128, 4, 1, 3, true>(batch, max_m, max_n, st);
+    prof_after(0, st);
+    return rc;
+}
+
+template <int BI, int BJ, int WI, int WJ, int NST>
+static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NST * ((BI + BJ) / 16) * 16 * kImgRowBytes;
+    static_assert(lds <= 160 * 1024 && (size_t)WI * WJ * 32 * 36 * 4 <= lds, "LDS ring / epilogue panels");
+    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST>;
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WI * WJ * 64), lds, st, a);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// rows per split are whole row blocks; the slabs (and the column-sum slabs behind them) are reduced by
+// the caller (launch_slab_reduce / the deferred queue) exactly like those of the fp32-operand kernels
+G3TnPlan g3_tn_plan(int ni, int nj, int64_t rows) {
+    G3TnPlan p;
+    p.variant = tune_get("g3_tn_variant", 0);
+    if (!p.variant) p.variant = 2;
+    const int bi = p.variant == 1 ? 256 : 128;
+    const int64_t tiles = cdiv(ni, bi) * cdiv(nj, 128);
+    int64_t s = cdiv(tune_get("g3_tn_wgs", p.variant == 1 ? 256 : 512), tiles);
+    const int64_t max_s = cdiv(rows, 256);  // at least 16 stages per split
+    if (s > max_s) s = max_s;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    const int64_t rps = cdiv(cdiv(rows, s), 32) * 32;
+    p.splits = (int)cdiv(rows, rps);
+    p.rows_per_split = rps;
+    return p;
+}
+size_t g3_tn_scratch_bytes(int ni, int nj, int64_t rows) {
+    const G3TnPlan p = g3_tn_plan(ni, nj, rows);
+    return ((size_t)p.splits * ni * nj + (size_t)p.splits * ni) * sizeof(float);
+}
+
+int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
+    if (!a.a3 || !a.b3 || !a.out || a.ni <= 0 || a.nj <= 0 || a.rows <= 0 || (a.rows & 31) || (a.a_row0 & 31) ||
+        (a.b_row0 & 31) || a.a_steps < img_steps(a.ni) || a.b_steps < img_steps(a.nj)) {
+        set_error("gemm_tn3: bad operand (ni=%d nj=%d rows=%lld)", a.ni, a.nj, (long long)a.rows);
+        return MARL_EINVAL;
+    }
+    // 32-bit offsets: column steps of an operand x one row block, and the row blocks of one split
+    if ((int64_t)(plan.rows_per_split >> 5) * a.a_steps * kImgChunkBytes >= (1ll << 31) ||
+        (int64_t)(plan.rows_per_split >> 5) * a.b_steps * kImgChunkBytes >= (1ll << 31)) {
+        set_error("gemm_tn3: split too long for 32-bit offsets");
+        return MARL_ELIMIT;
+    }
+    a.rows_per_split = plan.rows_per_split;
+    a.safe = tune_get("g3_safe", 0) != 0;
+    const int bi = plan.variant == 1 ? 256 : 128;
+    dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)cdiv(a.nj, 128), (unsigned)plan.splits);
+    a.gx = a.gy = a.gz = 0;
+    if (tune_get("tn_xcd", 1)) {
+        a.gx = (int)grid.x;
+        a.gy = (int)grid.y;
+        a.gz = (int)grid.z;
+        grid = dim3(grid.x * grid.y * grid.z);
+    }
+    prof_before(2, st);
+    int rc;
+    if (plan.variant == 1)
+        rc = launch_tn3_variant<256, 128, 4, 2, 4>(a, grid, st);
+    else
+        rc = launch_tn3_variant<128, 128, 2, 2, 3>(a, grid, st);
+    prof_after(2, st);
+    return rc;
+}
+
+}  // namespace marl
+
+// ---------------------------------------------------------------------------
+// kernel-level C ABI (tests, tools; include/marl_hip.h)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+size_t marl_image_bytes(int64_t rows, int k) { return rows > 0 && k > 0 ? marl::img_bytes(rows, k) : 0; }
+
+int marl_image_build(const float* src, int ld, int64_t rows, int k, void* image, void* stream) {
+    using namespace marl;
+    if (!src || !image || rows < 1 || k < 1 || ld < k || (reinterpret_cast<uintptr_t>(image) & 15)) {
+        set_error("image_build: bad argument");
+        return MARL_EINVAL;
+    }
+    ImgBatch b{};
+    b.d[0] = ImgDesc{src, image, rows, k, ld};
+    b.count = 1;
+    return launch_images(b, static_cast<hipStream_t>(stream));
+}
+
+int marl_gemm_nt_images(const void* a3, const void* b3, const float* bias, float* c, int ldc, int m, int n,
+                        int k, int accumulate, int variant, void* stream) {
+    using namespace marl;
+    if (k < 1) return MARL_EINVAL;
+    G3Batch bt{};
+    bt.p[0] = g3_prob(a3, 0, b3, 0, k, c, ldc, m, n, bias, accumulate);
+    bt.count = 1;
+    return launch_gemm_nt3(bt, static_cast<hipStream_t>(stream), variant);
+}
+
+// `count` products of equal M and K in one launch (the in-loop backward batch)
+int marl_gemm_nt_images_batch(int count, const void* const* a3, const void* const* b3, float* const* c,
+                              const int* n, const int* ldc, int m, int k, int accumulate, int variant,
+                              void* stream) {
+    using namespace marl;
+    if (count < 1 || count > kMaxG3 || k < 1 || !a3 || !b3 || !c || !n || !ldc) return MARL_EINVAL;
+    G3Batch bt{};
+    for (int i = 0; i < count; ++i)
+        bt.p[i] = g3_prob(a3[i], 0, b3[i], 0, k, c[i], ldc[i], m, n[i], nullptr, accumulate);
+    bt.count = count;
+    return launch_gemm_nt3(bt, static_cast<hipStream_t>(stream), variant);
+}
+
+// one LSTM cell: gates = u3 * wih3^T + h3 * whh3^T + bias, fused cell update; h3_next nullable
+// (cells = 2: the same problem twice in one launch - the two-cell launch of the episode, for timing)
+int marl_lstm_images(const void* u3, int nin, const void* h3, const void* wih3, const void* whh3,
+                     const float* bias, const float* c_prev, float* h_next, float* c_next, float* gates,
+                     void* h3_next, int m, int n, int ld_state, int ld_gates, int variant, int cells,
+                     void* stream) {
+    using namespace marl;
+    if (nin < 1 || n < 1) return MARL_EINVAL;
+    G3Batch bt{};
+    G3Prob& p = bt.p[0];
+    p = g3_prob(u3, 0, wih3, 0, nin, nullptr, 0, m, n, bias);
+    g3_add_seg(p, h3, 0, whh3, 0, n);
+    p.c_prev = c_prev;
+    p.h_next = h_next;
+    p.c_next = c_next;
+    p.gates = gates;
+    p.ld_state = ld_state;
+    p.ld_gates = ld_gates;
+    p.h3 = static_cast<char*>(h3_next);
+    p.h3_row0 = 0;
+    p.h3_steps = img_steps(n);
+    bt.count = 1;
+    if (cells == 2) {
+        bt.p[1] = p;
+        bt.count = 2;
+    }
+    return launch_gemm_lstm3(bt, static_cast<hipStream_t>(stream), variant);
+}
+
+// C[NI,NJ] = sum_r A[r,i] B[r,j] from images whose rows are the contraction index (rows % 32 == 0);
+// colsum (nullable) [NI] = column sums of A; scratch >= marl_gemm_tn_images_scratch() bytes
+size_t marl_gemm_tn_images_scratch(int ni, int nj, int64_t rows) { return marl::g3_tn_scratch_bytes(ni, nj, rows); }
+int marl_gemm_tn_images(const void* a3, const void* b3, float* c, int ldc, int ni, int nj, int64_t rows,
+                        float* colsum, float* scratch, size_t scratch_bytes, void* stream) {
+    using namespace marl;
+    if (!scratch || scratch_bytes < g3_tn_scratch_bytes(ni, nj, rows)) {
+        set_error("gemm_tn_images: scratch too small");
+        return MARL_ESIZE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const G3TnPlan plan = g3_tn_plan(ni, nj, rows);
+    G3TnArgs a{};
+    a.a3 = static_cast<const char*>(a3);
+    a.b3 = static_cast<const char*>(b3);
+    a.a_steps = img_steps(ni);
+    a.b_steps = img_steps(nj);
+    a.out = scratch;
+    a.ldo = nj;
+    a.out_split_stride = (int64_t)ni * nj;
+    a.ni = ni;
+    a.nj = nj;
+    a.rows = rows;
+    a.csum = colsum ? scratch + (size_t)plan.splits * ni * nj : nullptr;
+    MARL_TRY(launch_gemm_tn3(a, plan, st));
+    return launch_slab_reduce(scratch, (int64_t)ni * nj, plan.splits, c, ldc, ni, nj, a.csum, colsum, st);
+}
+
+}  // extern "C"

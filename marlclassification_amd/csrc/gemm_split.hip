@@ -42,17 +42,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// two fp32 values -> one dword (x low half, y high half) per bf16 term
-__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
-    const f32x2_t v = {x, y};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));  // v_cvt_pk_bf16_f32 (RNE)
-}
-__device__ __forceinline__ void split_pair(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pack_bf16(x, y);
-    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
-    p1 = pack_bf16(rx, ry);
-    p2 = pack_bf16(rx - __uint_as_float(p1 << 16), ry - __uint_as_float(p1 & 0xffff0000u));
-}
+// (pack_bf16 / split_pair: split.h)
 // four consecutive-k values -> 8 bytes in each of the three planes
 __device__ __forceinline__ void split_store4(char* dst, int plane, float a, float b, float c, float d) {
     uint32_t a0, a1, a2, b0, b1, b2;

@@ -539,8 +539,11 @@ template <bool CELL>
 __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (CELL && (int)blockIdx.x >= P.panel_blocks) {
-        lstm_cell_bwd_elem(P.cell, P.cell_rows,
-                           (int64_t)((int)blockIdx.x - P.panel_blocks) * blockDim.x + threadIdx.x);
+        const int64_t idx = (int64_t)((int)blockIdx.x - P.panel_blocks) * blockDim.x + threadIdx.x;
+        if (P.cell_vec4)
+            lstm_cell_bwd_elem4(P.cell, P.cell_rows, idx);
+        else
+            lstm_cell_bwd_elem(P.cell, P.cell_rows, idx);
         return;
     }
     const int m0 = blockIdx.x * kPanelRows;
@@ -890,6 +893,14 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                         *reinterpret_cast<float4*>(g + 3 * cn) = make_float4(o3[0], o3[1], o3[2], o3[3]);
                         *reinterpret_cast<float4*>(Cb.dc + (size_t)rowi[k] * Cb.lddc + coli[k]) =
                             make_float4(o4[0], o4[1], o4[2], o4[3]);
+                        if (Cb.g3) {  // the k16 image of the gate gradients (A operand of the image GEMMs)
+                            const int64_t ir = (int64_t)Cb.g3_row0 + rowi[k];
+                            const int c0 = coli[k];
+                            img_store4(Cb.g3 + img_off(ir, c0 >> 4, Cb.g3_steps), c0, o0[0], o0[1], o0[2], o0[3]);
+                            img_store4(Cb.g3 + img_off(ir, (cn + c0) >> 4, Cb.g3_steps), cn + c0, o1[0], o1[1], o1[2], o1[3]);
+                            img_store4(Cb.g3 + img_off(ir, (2 * cn + c0) >> 4, Cb.g3_steps), 2 * cn + c0, o2[0], o2[1], o2[2], o2[3]);
+                            img_store4(Cb.g3 + img_off(ir, (3 * cn + c0) >> 4, Cb.g3_steps), 3 * cn + c0, o3[0], o3[1], o3[2], o3[3]);
+                        }
                     }
                 }
             }
@@ -963,9 +974,12 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     }
     const unsigned pblocks = p.by_batch > 0 ? (unsigned)cdiv(p.g_nb, p.by_batch) : (unsigned)cdiv(p.m, kPanelRows);
     prof_before(4, st);
+    p.cellb_img_done = p.has_cellb && p.cellb.g3 && tail_lds;
+    p.cell_vec4 = p.has_cell && lstm_bwd_vec4_ok(p.cell);
+    p.cell_img_done = p.has_cell && p.cell.g3 && p.cell_vec4;
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
-        const unsigned cblocks = (unsigned)cdiv(p.cell_rows * p.cell.n, 64 * waves);
+        const unsigned cblocks = (unsigned)cdiv(p.cell_rows * (p.cell_vec4 ? p.cell.n / 4 : p.cell.n), 64 * waves);
         hipLaunchKernelGGL(panel_bwd_kernel<true>, dim3(pblocks + cblocks), dim3(64 * waves), lds, st, p);
     } else {
         hipLaunchKernelGGL(panel_bwd_kernel<false>, dim3(pblocks), dim3(64 * waves), lds, st, p);

@@ -1113,19 +1113,38 @@ int launch_pos_embed_fwd(const int32_t* pos, const float* npos_in, int h, int w,
 // pre-activation gradients on exit; dc holds dL/dc_t on entry and dL/dc_{t-1} on exit.
 // ---------------------------------------------------------------------------
 __global__ void lstm_cell_bwd_kernel(const LstmBwdBatch B) {
-    lstm_cell_bwd_elem(B.a[blockIdx.y], B.rows, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (B.vec4)
+        lstm_cell_bwd_elem4(B.a[blockIdx.y], B.rows, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    else
+        lstm_cell_bwd_elem(B.a[blockIdx.y], B.rows, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+int launch_lstm_cell_bwd_batch(LstmBwdBatch& b, int count, hipStream_t st) {
+    int nmax = 0;
+    b.vec4 = 1;
+    for (int i = 0; i < count; ++i) {
+        nmax = b.a[i].n > nmax ? b.a[i].n : nmax;
+        if (!lstm_bwd_vec4_ok(b.a[i])) b.vec4 = 0;
+    }
+    if (!b.vec4)
+        for (int i = 0; i < count; ++i)
+            if (b.a[i].g3) {
+                set_error("lstm_cell_bwd: the gate-gradient image needs the 4-wide form");
+                return MARL_EINVAL;
+            }
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(b.rows * (b.vec4 ? nmax / 4 : nmax), 256), (unsigned)count),
+                       dim3(256), 0, st, b);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
 }
 
 int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* gates, int ldg,
                          const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
                          hipStream_t st) {
     LstmBwdBatch b{};
-    b.a[0] = LstmBwdArgs{dh, dc, gates, c_prev, c_new, lddh, lddc, ldg, ldc, n};
+    b.a[0] = LstmBwdArgs{dh, dc, gates, c_prev, c_new, lddh, lddc, ldg, ldc, n, nullptr, 0, 0};
     b.rows = rows;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(rows * n, 256), 1), dim3(256), 0, st,
-                       b);
-    MARL_LAUNCH_CHECK();
-    return MARL_OK;
+    return launch_lstm_cell_bwd_batch(b, 1, st);
 }
 
 // belief and action cells in one launch
@@ -1135,14 +1154,10 @@ int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, fl
                           int ldg1, const float* cp1, const float* cn1, int ldc1, int n1,
                           int64_t rows, hipStream_t st) {
     LstmBwdBatch b{};
-    b.a[0] = LstmBwdArgs{dh0, dc0, gates0, cp0, cn0, lddh0, lddc0, ldg0, ldc0, n0};
-    b.a[1] = LstmBwdArgs{dh1, dc1, gates1, cp1, cn1, lddh1, lddc1, ldg1, ldc1, n1};
+    b.a[0] = LstmBwdArgs{dh0, dc0, gates0, cp0, cn0, lddh0, lddc0, ldg0, ldc0, n0, nullptr, 0, 0};
+    b.a[1] = LstmBwdArgs{dh1, dc1, gates1, cp1, cn1, lddh1, lddc1, ldg1, ldc1, n1, nullptr, 0, 0};
     b.rows = rows;
-    const int nmax = n0 > n1 ? n0 : n1;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv(rows * nmax, 256), 2), dim3(256), 0,
-                       st, b);
-    MARL_LAUNCH_CHECK();
-    return MARL_OK;
+    return launch_lstm_cell_bwd_batch(b, 2, st);
 }
 
 // ---------------------------------------------------------------------------
