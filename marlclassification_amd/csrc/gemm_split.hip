@@ -6,7 +6,9 @@
 // with x0 + x1 + x2 == x EXACTLY (3 x 8 significand bits + the signs cover fp32's 24), and a
 // product a*b is accumulated in fp32 from the six bf16 x bf16 MFMA products of weight >= 2^-16,
 //     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0);
-// the three dropped terms are below 2^-25 |a b|, i.e. under fp32's own rounding step.  Every
+// the three dropped terms a1 b2 + a2 b1 + a2 b2 are bounded by 2^-23 |a b| (|x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|
+// with round-to-nearest splits), i.e. two fp32 unit round-offs in the worst case - measured, the error equals the
+// exact-fp32 MFMA kernels' (tests/test_gpu_kernels.py asserts err <= 1.5 x theirs per shape).  Every
 // bf16 x bf16 product is exact in fp32, so the result differs from an fp32 fmaf chain only in
 // summation order - measured against float64: max error <= the fp32-MFMA kernel's on every
 // shape of this workload (tests/test_gpu_kernels.py::test_split_gemm_*).  Six
