@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MARL_ABI_VERSION 2
+#define MARL_ABI_VERSION 3
 
 #define MARL_OK 0
 #define MARL_EINVAL (-1)   /* bad configuration / null pointer          */
@@ -107,14 +107,18 @@ int64_t marl_param_numel(const marl_config* cfg, int index);
 /* Byte sizes of the two caller-owned workspaces:
  *   weights_ws : padded / transposed copies of the parameters + packed gradients
  *   episode_ws : every per-step activation of one episode (saved for backward)
- * `train` = 0 sizes episode_ws for rollout only (nothing kept for backward). */
+ * `train` = 0 sizes episode_ws for rollout only (nothing kept for backward).
+ * ABI 3: every entry point that takes a workspace also takes its size in bytes and returns
+ * MARL_ESIZE (nothing enqueued) when the layout for the CURRENT configuration and tuning knobs does
+ * not fit - e.g. a buffer allocated before a layout-affecting marl_tune() call.  (marl_a2c_loss_fwd_bwd
+ * wants the TRAINING size: its scratch is the tail of that layout.) */
 int marl_workspace_sizes(const marl_config* cfg, int train,
                          size_t* weights_ws_bytes, size_t* episode_ws_bytes);
 
 /* Re-packs the parameters into weights_ws; call after every optimiser step and
  * after load_state_dict (replaces nothing in the reference - layout plumbing). */
 int marl_pack_weights(const marl_config* cfg, const float* const* params_host,
-                      void* weights_ws, void* stream);
+                      void* weights_ws, size_t weights_ws_bytes, void* stream);
 
 /* Environment.__observation (core/environment.py:95-126): coalesced patch gather.
  * img [Nb,C,H,W] fp32, pos int64 [Na*Nb,2] -> obs [Na*Nb, C, f, f] fp32. */
@@ -168,7 +172,8 @@ int marl_graph_destroy(void* graph_exec);
  * Outputs: step_preds [Ns,R,nC], step_logp [Ns,R], step_values [Ns,R],
  * step_pos int64 [Ns,R,2] (after move t), step_actions int64 [Ns,R] (may be NULL).
  * With train != 0 the activations needed by marl_episode_backward stay in episode_ws. */
-int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+int marl_episode_forward(const marl_config* cfg, const void* weights_ws, size_t weights_ws_bytes,
+                         void* episode_ws, size_t episode_ws_bytes,
                          const void* img, const int64_t* pos0,
                          const float* h0, const float* c0, const float* hc0, const float* cc0,
                          const float* noise, const int64_t* forced_actions,
@@ -184,7 +189,8 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
  * marl_episode_forward(train = 1) call: the first convolution's weight gradient re-gathers
  * the patches at the saved positions instead of keeping im2col rows in episode_ws (autograd
  * would keep the observation tensors alive the same way). */
-int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
+int marl_episode_backward(const marl_config* cfg, void* weights_ws, size_t weights_ws_bytes,
+                          void* episode_ws, size_t episode_ws_bytes,
                           const void* img, const float* g_preds, const float* g_logp,
                           const float* g_values, float* const* grads_host, void* stream);
 
@@ -195,7 +201,7 @@ int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episod
  *   phase 0 = everything local (single GPU); phase 1 = only write local
  *   (n, sum x, sum x^2) of the advantages to adv_stats[3] (caller all-reduces them);
  *   phase 2 = finish using the all-reduced adv_stats. */
-int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws,
+int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, size_t episode_ws_bytes,
                           const float* step_preds, const float* step_logp,
                           const float* step_values, const int64_t* y, float gamma,
                           float* g_preds, float* g_logp, float* g_values,
@@ -213,7 +219,8 @@ int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  * (networks/models.py:78-138, core/agent.py:40-68): obs [R,C,f,f] is gathered by the
  * caller (marl_patch_gather); msg [R,n_m]; norm_pos [R,2]; state in h,c,hc,cc.
  * Outputs: probs [R,nA], values [R], preds [R,nC], new_msg [R,n_m], new state. */
-int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
+int marl_step_forward(const marl_config* cfg, const void* weights_ws, size_t weights_ws_bytes,
+                      void* episode_ws, size_t episode_ws_bytes,
                       const float* obs, const float* msg, const float* norm_pos,
                       const float* h, const float* c, const float* hc, const float* cc,
                       float* probs, float* values, float* preds, float* new_msg,
@@ -293,8 +300,8 @@ size_t marl_cnn_wgrad_scratch(int64_t rows, int cin, int cout, int hin, int grou
  * environment variables, lower case, e.g. "wgrad_rb", "mfma_split"); tools/ and tests only.
  * Several knobs change the LAYOUT of the episode workspace (tile plans, split-K targets,
  * mfma_split ...): marl_workspace_sizes() must be asked again and the workspace re-allocated
- * after such a call - the library never sees the size of the buffer it is handed.  (The Python
- * wrapper marlclassification_amd.engine.tune() drops every cached workspace.) */
+ * after such a call; a stale buffer is refused with MARL_ESIZE (ABI 3: sizes are passed in).  (The
+ * Python wrapper marlclassification_amd.engine.tune() drops every cached workspace.) */
 int marl_tune(const char* key, int value);
 /* current value of a knob (marl_tune value, else MARL_<KEY>, else dflt) */
 int marl_tune_get(const char* key, int dflt);
@@ -308,7 +315,8 @@ int marl_profile_begin(int kernel_class, int max_launches);
 int marl_profile_end(double* total_ms, int* launches);
 
 /* test hook: float offset and leading dimension of a named per-step activation inside
- * episode_ws ("U","H","C","HC","CC","MSG","PROBS","COLS0","Z0","GB","DU","DH","DHC"). */
+ * episode_ws ("U","H","C","HC","CC","MSG","PROBS","COLS0","Z0","GB","DU","DH","DHC"), or - "WP<i>" /
+ * "WT<i>" - of the packed / transposed fp32 copy of parameter slot i inside weights_ws. */
 int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t,
                       int64_t* offset_floats, int* ld);
 

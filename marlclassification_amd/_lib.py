@@ -13,7 +13,7 @@ from typing import Optional
 
 MARL_MAX_CNN_LAYERS = 5
 MARL_MAX_ACTIONS = 16
-MARL_ABI_VERSION = 2
+MARL_ABI_VERSION = 3
 MARL_COUNTERS_BYTES = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -87,10 +87,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_param_numel.restype = _i64
     lib.marl_param_numel.argtypes = [_cfgp, _i]
     lib.marl_workspace_sizes.argtypes = [_cfgp, _i, C.POINTER(_sz), C.POINTER(_sz)]
-    lib.marl_pack_weights.argtypes = [_cfgp, C.POINTER(_vp), _vp, _vp]
+    lib.marl_pack_weights.argtypes = [_cfgp, C.POINTER(_vp), _vp, _sz, _vp]
     lib.marl_patch_gather.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.marl_transition.argtypes = [_vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _vp]
-    lib.marl_episode_forward.argtypes = ([_cfgp, _vp, _vp] + [_vp] * 8 + [_u64, _u64, _vp] + [_vp] * 5 +
+    lib.marl_episode_forward.argtypes = ([_cfgp, _vp, _sz, _vp, _sz] + [_vp] * 8 + [_u64, _u64, _vp] + [_vp] * 5 +
                                          [_i, _vp])
     lib.marl_draw_episode.argtypes = [_cfgp, _u64, _u64, _vp] + [_vp] * 7
     lib.marl_counters_set.argtypes = [_vp, _u64, _i64, _f, _f, _f, _vp]
@@ -99,12 +99,12 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_graph_end.argtypes = [_vp, C.POINTER(_vp)]
     lib.marl_graph_launch.argtypes = [_vp, _vp]
     lib.marl_graph_destroy.argtypes = [_vp]
-    lib.marl_episode_backward.argtypes = [_cfgp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]
+    lib.marl_episode_backward.argtypes = [_cfgp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]
     lib.marl_a2c_loss_fwd_bwd.argtypes = (
-        [_cfgp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
+        [_cfgp, _vp, _sz, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
     )
     lib.marl_adam_step.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _vp, _vp]
-    lib.marl_step_forward.argtypes = ([_cfgp, _vp, _vp] + [_vp] * 15 + [_vp, _u64, _u64, _vp, _vp] +
+    lib.marl_step_forward.argtypes = ([_cfgp, _vp, _sz, _vp, _sz] + [_vp] * 15 + [_vp, _u64, _u64, _vp, _vp] +
                                       [_vp])
     lib.marl_normalize_positions.argtypes = [_vp, _vp, _i, _i, _i, _vp]
     lib.marl_gemm_nt.argtypes = [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]

@@ -149,6 +149,11 @@ int launch_split_weights(const SplitBatch& b, hipStream_t st);
 // workspace; the launchers look the B operands of a product up in it
 void split_registry_reset();
 void split_registry_add(const float* base, int rows, int ld, int k, const void* image);
+struct SplitRegistryScope {  // clears the table when the registering entry point returns
+    SplitRegistryScope() = default;
+    SplitRegistryScope(const SplitRegistryScope&) = delete;
+    ~SplitRegistryScope() { split_registry_reset(); }
+};
 int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st);
 int launch_gemm_lstm_split(const GemmBatch& batch, int max_m, int max_n, hipStream_t st);
 int launch_gemm_tn_split(const float* a, int lda, const float* b, int ldb, float* out, int ldo,

@@ -532,11 +532,17 @@ struct Ctx {
 
 static void register_split_images(const Dims& d, const WLayout& w, const float* W);
 
-static int make_ctx(const marl_config* cfg, const void* wws, void* ews, int train, void* stream,
-                    Ctx& c) {
+static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void* ews, size_t ebytes,
+                    int train, void* stream, Ctx& c) {
     MARL_TRY(make_dims(cfg, c.d));
     make_wlayout(c.d, c.w);
     make_elayout(c.d, train, c.e);
+    if (wbytes < c.w.total * sizeof(float) || ebytes < c.e.total * sizeof(float)) {
+        set_error("workspace too small for the current configuration / tuning knobs: weights %zu of %zu "
+                  "bytes, episode %zu of %zu bytes (ask marl_workspace_sizes again)", wbytes,
+                  c.w.total * sizeof(float), ebytes, c.e.total * sizeof(float));
+        return MARL_ESIZE;
+    }
     c.W = const_cast<float*>(static_cast<const float*>(wws));
     c.E = static_cast<float*>(ews);
     c.st = static_cast<hipStream_t>(stream);
@@ -1623,7 +1629,7 @@ int marl_workspace_sizes(const marl_config* cfg, int train, size_t* wbytes, size
 }
 
 int marl_pack_weights(const marl_config* cfg, const float* const* params_host, void* weights_ws,
-                      void* stream) {
+                      size_t weights_ws_bytes, void* stream) {
     Dims d;
     MARL_TRY(make_dims(cfg, d));
     if (!params_host || !weights_ws) {
@@ -1632,6 +1638,11 @@ int marl_pack_weights(const marl_config* cfg, const float* const* params_host, v
     }
     WLayout w;
     make_wlayout(d, w);
+    if (weights_ws_bytes < w.total * sizeof(float)) {
+        set_error("pack_weights: weights workspace too small (%zu of %zu bytes)", weights_ws_bytes,
+                  w.total * sizeof(float));
+        return MARL_ESIZE;
+    }
     return pack_weights(d, w, params_host, static_cast<float*>(weights_ws),
                         static_cast<hipStream_t>(stream));
 }
@@ -1688,15 +1699,16 @@ int marl_transition(const int64_t* pos_in, const int64_t* actions, int64_t* pos_
     return MARL_OK;
 }
 
-int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
-                         const void* img, const int64_t* pos0, const float* h0, const float* c0,
+int marl_episode_forward(const marl_config* cfg, const void* weights_ws, size_t weights_ws_bytes,
+                         void* episode_ws, size_t episode_ws_bytes, const void* img, const int64_t* pos0, const float* h0, const float* c0,
                          const float* hc0, const float* cc0, const float* noise,
                          const int64_t* forced_actions, uint64_t rng_seed, uint64_t rng_offset,
                          const void* counters, float* step_preds, float* step_logp,
                          float* step_values, int64_t* step_pos, int64_t* step_actions, int train,
                          void* stream) {
     Ctx c;
-    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, train, stream, c));
+    SplitRegistryScope reg_scope;
+    MARL_TRY(make_ctx(cfg, weights_ws, weights_ws_bytes, episode_ws, episode_ws_bytes, train, stream, c));
     if (!img || !pos0 || !h0 || !c0 || !hc0 || !cc0 || !step_preds || !step_logp || !step_values) {
         set_error("episode_forward: null argument");
         return MARL_EINVAL;
@@ -1770,11 +1782,12 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, void* e
     return heads_batched(c, 0, d.NR, step_values, step_preds);
 }
 
-int marl_episode_backward(const marl_config* cfg, void* weights_ws, void* episode_ws,
-                          const void* img, const float* g_preds, const float* g_logp,
+int marl_episode_backward(const marl_config* cfg, void* weights_ws, size_t weights_ws_bytes,
+                          void* episode_ws, size_t episode_ws_bytes, const void* img, const float* g_preds, const float* g_logp,
                           const float* g_values, float* const* grads_host, void* stream) {
     Ctx c;
-    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 1, stream, c));
+    SplitRegistryScope reg_scope;
+    MARL_TRY(make_ctx(cfg, weights_ws, weights_ws_bytes, episode_ws, episode_ws_bytes, 1, stream, c));
     if (!grads_host) {
         set_error("episode_backward: null gradient table");
         return MARL_EINVAL;
@@ -1852,7 +1865,8 @@ int marl_graph_destroy(void* graph_exec) {
     return MARL_OK;
 }
 
-int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float* step_preds,
+int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, size_t episode_ws_bytes,
+                          const float* step_preds,
                           const float* step_logp, const float* step_values, const int64_t* y,
                           float gamma, float* g_preds, float* g_logp, float* g_values,
                           float* scalars_out, double* adv_stats, int phase, void* stream) {
@@ -1866,6 +1880,11 @@ int marl_a2c_loss_fwd_bwd(const marl_config* cfg, void* episode_ws, const float*
     // the loss scratch is the last buffer of either episode-workspace layout
     ELayout e;
     make_elayout(d, 1, e);
+    if (episode_ws_bytes < e.total * sizeof(float)) {
+        set_error("a2c_loss: episode workspace too small (%zu of %zu bytes, training layout)", episode_ws_bytes,
+                  e.total * sizeof(float));
+        return MARL_ESIZE;
+    }
     LossArgs a;
     a.preds = step_preds;
     a.logp = step_logp;
@@ -1901,14 +1920,15 @@ int marl_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                        static_cast<hipStream_t>(stream), static_cast<const Counters*>(counters));
 }
 
-int marl_step_forward(const marl_config* cfg, const void* weights_ws, void* episode_ws,
-                      const float* obs, const float* msg, const float* norm_pos, const float* h,
+int marl_step_forward(const marl_config* cfg, const void* weights_ws, size_t weights_ws_bytes,
+                      void* episode_ws, size_t episode_ws_bytes, const float* obs, const float* msg, const float* norm_pos, const float* h,
                       const float* cc_, const float* hc, const float* cca, float* probs,
                       float* values, float* preds, float* new_msg, float* h_out, float* c_out,
                       float* hc_out, float* cc_out, const float* noise, uint64_t rng_seed,
                       uint64_t rng_offset, int64_t* actions_out, float* logp_out, void* stream) {
     Ctx c;
-    MARL_TRY(make_ctx(cfg, weights_ws, episode_ws, 0, stream, c));
+    SplitRegistryScope reg_scope;
+    MARL_TRY(make_ctx(cfg, weights_ws, weights_ws_bytes, episode_ws, episode_ws_bytes, 0, stream, c));
     if (!obs || !msg || !norm_pos || !h || !cc_ || !hc || !cca || !probs || !values || !preds ||
         !new_msg || !h_out || !c_out || !hc_out || !cc_out) {
         set_error("step_forward: null argument");
@@ -1958,6 +1978,16 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
         *ld = l;
         return MARL_OK;
     };
+    if (!strncmp(name, "WP", 2) || !strncmp(name, "WT", 2)) {  // weights workspace: packed / transposed copy of parameter <idx>
+        const int idx = atoi(name + 2);
+        WLayout w;
+        make_wlayout(d, w);
+        if (idx < 0 || idx >= MARL_NPARAMS || param_meta(d, idx).kind == PK_NONE) {
+            set_error("no parameter %d", idx);
+            return MARL_EINVAL;
+        }
+        return name[1] == 'P' ? set(w.wp[idx], w.ldp[idx]) : set(w.wt[idx], w.ldt[idx]);
+    }
     if (!strcmp(name, "U")) return set(e.U.at(ts), d.ld_nin);
     if (!strcmp(name, "H")) return set(e.H + (size_t)t * R * d.ld_nb, d.ld_nb);
     if (!strcmp(name, "C")) return set(e.C + (size_t)t * R * d.ld_nb, d.ld_nb);
@@ -2015,6 +2045,7 @@ int marl_profile_end(double* total_ms, int* launches) { return profile_end(total
 // ---- kernel-level entry points -------------------------------------------------------
 int marl_gemm_nt(const float* a, int lda, const float* b, int ldb, const float* bias, float* c,
                  int ldc, int m, int n, int k, int accumulate, void* stream) {
+    split_registry_reset();  // plain fp32 operands: no image of B is known to this call
     GemmBatch bt{};
     bt.p[0] = gemm_prob(a, lda, b, ldb, k, c, ldc, m, n, bias, accumulate);
     bt.count = 1;

@@ -619,8 +619,11 @@ struct SplitReg {
     int ld, k;
     const char* image;
 };
-SplitReg g_reg[kMaxSplitDesc];
-int g_nreg = 0;
+// (per THREAD and per CALL: ctypes releases the GIL, two engines may be inside the library at once; every
+// entry point that registers clears the table again before it returns - SplitRegistryScope - so a later
+// kernel-level call can never meet the image of a workspace that was freed or rewritten since)
+thread_local SplitReg g_reg[kMaxSplitDesc];
+thread_local int g_nreg = 0;
 // b = base + row0 * ld of a registered matrix with the same row stride and depth -> its image rows
 bool split_lookup(const GemmSeg& g, const void*& b3, int& kt) {
     for (int i = 0; i < g_nreg; ++i) {

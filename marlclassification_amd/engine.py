@@ -137,6 +137,10 @@ def tune(key: str, value: int) -> None:
     _tune_epoch += 1
 
 
+def _nbytes(t: th.Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
 def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -262,8 +266,9 @@ class HipEngine:
     def pack(self, params: Dict[str, th.Tensor]) -> None:
         """marl_pack_weights: refresh the padded / transposed copies after an update."""
         assert self.cfg is not None, "configure() first"
-        check(self.lib.marl_pack_weights(C.byref(self.cfg), self._table(params),
-                                         self.weights_ws().data_ptr(), _stream(self.device)))
+        wws = self.weights_ws()
+        check(self.lib.marl_pack_weights(C.byref(self.cfg), self._table(params), wws.data_ptr(), _nbytes(wws),
+                                         _stream(self.device)))
         self.pack_generation += 1
 
     def episode_forward(
@@ -292,9 +297,9 @@ class HipEngine:
         seed, offset = rng if rng is not None else (0, 0)
         if out is None:  # (graph capture passes persistent output tensors: nothing may allocate)
             out = self.new_outputs()
+        wws, ews = self.weights_ws(), (ws if ws is not None else self.episode_ws(train))
         check(self.lib.marl_episode_forward(
-            C.byref(cfg), self.weights_ws().data_ptr(),
-            (ws if ws is not None else self.episode_ws(train)).data_ptr(),
+            C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             img.data_ptr(), pos0.data_ptr(), h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(),
             cc0.data_ptr(), _ptr(noise), _ptr(forced_actions), seed & _U64, offset & _U64,
             _ptr(counters), out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(),
@@ -336,8 +341,9 @@ class HipEngine:
             gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
             gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
             gv = None if g_values is None else _need(g_values, th.float32, "g_values")
+            wws = self.weights_ws()
             check(self.lib.marl_episode_backward(
-                C.byref(cfg), self.weights_ws().data_ptr(), ws.data_ptr(), img.data_ptr(), _ptr(gp),
+                C.byref(cfg), wws.data_ptr(), _nbytes(wws), ws.data_ptr(), _nbytes(ws), img.data_ptr(), _ptr(gp),
                 _ptr(gl), _ptr(gv), self._table(grads), _stream(self.device)))
             return
         if self._fwd_img is None or self._fwd_key != self._cfg_key:
@@ -353,8 +359,9 @@ class HipEngine:
         gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
         gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
         gv = None if g_values is None else _need(g_values, th.float32, "g_values")
+        wws, ews = self.weights_ws(), self.episode_ws(True)
         check(self.lib.marl_episode_backward(
-            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(True).data_ptr(),
+            C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             self._fwd_img.data_ptr(), _ptr(gp), _ptr(gl), _ptr(gv), self._table(grads),
             _stream(self.device)))
 
@@ -374,8 +381,9 @@ class HipEngine:
                 th.zeros(3, dtype=th.float64, device=dev),
             )
         gp, gl, gv, sc, st = bufs
+        ews = self.episode_ws(True)
         check(self.lib.marl_a2c_loss_fwd_bwd(
-            C.byref(cfg), self.episode_ws(True).data_ptr(), out.step_preds.data_ptr(),
+            C.byref(cfg), ews.data_ptr(), _nbytes(ews), out.step_preds.data_ptr(),
             out.step_log_probas.data_ptr(), out.step_values.data_ptr(), y.data_ptr(),
             C.c_float(gamma), gp.data_ptr(), gl.data_ptr(), gv.data_ptr(), sc.data_ptr(),
             st.data_ptr(), phase, _stream(dev)))
@@ -423,8 +431,9 @@ class HipEngine:
             lp = th.empty(na, nb, device=dev)
             extra = (act, lp)
         seed, offset = rng if rng is not None else (0, 0)
+        wws, ews = self.weights_ws(), self.episode_ws(False)
         check(self.lib.marl_step_forward(
-            C.byref(cfg), self.weights_ws().data_ptr(), self.episode_ws(False).data_ptr(),
+            C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _ptr(nz), seed & _U64,
             offset & _U64, _ptr(act), _ptr(lp), _stream(dev)))
         return outs + extra

@@ -1,0 +1,125 @@
+"""GPU, round 4: the ABI sees workspace sizes (MARL_ESIZE instead of out-of-bounds writes), the bf16x3 weight-image
+registry is scoped to the call that filled it, and the image-GEMM path of the episode (csrc/gemm3.hip) is the
+one the parity fixtures with R % 32 == 0 run - checked against the fp32-operand path on the same episode."""
+import ctypes as C
+
+import pytest
+import torch as th
+
+from tests.util import Golden, model_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(g, device):
+    from marlclassification_amd.engine import HipEngine
+
+    eng = HipEngine(model_spec(g.cfg), device)
+    eng.configure(g.na, g.nb, g.ns, g.img.shape[1:])
+    eng.pack({k: v.to(device) for k, v in g.params.items()})
+    return eng
+
+
+def _forward(eng, g, device, train=True):
+    i = g.inp
+    return eng.episode_forward(g.img.to(device), i.pos0.to(device), i.h0.to(device), i.c0.to(device),
+                               i.hc0.to(device), i.cc0.to(device), i.q.to(device), None, train)
+
+
+def _raw_forward(eng, g, device, wws, wbytes, ews, ebytes, train=1):
+    """marl_episode_forward through ctypes with explicit workspace sizes; returns the status code"""
+    from marlclassification_amd.engine import _stream
+
+    i = g.inp
+    t = [x.to(device).contiguous() for x in (g.img, i.pos0, i.h0, i.c0, i.hc0, i.cc0, i.q)]
+    out = eng.new_outputs()
+    return eng.lib.marl_episode_forward(
+        C.byref(eng.cfg), wws.data_ptr(), wbytes, ews.data_ptr(), ebytes, *[x.data_ptr() for x in t], None, 0, 0, None,
+        out.step_preds.data_ptr(), out.step_log_probas.data_ptr(), out.step_values.data_ptr(), out.step_pos.data_ptr(),
+        out.step_actions.data_ptr(), train, _stream(device))
+
+
+def test_workspace_sizes_are_checked_by_the_abi(device):
+    """a buffer sized before a layout knob changed is refused with MARL_ESIZE (-4)"""
+    from marlclassification_amd import engine as E
+
+    g = Golden("g4_resisc_b2")  # R = 32: the image-GEMM layout (knob g3) adds the gate-gradient images
+    try:
+        E.tune("g3", 0)
+        eng = _engine(g, device)
+        wws, ews = eng.weights_ws(), eng.episode_ws(True)
+        sz_w, sz_e = C.c_size_t(0), C.c_size_t(0)
+        E.check(eng.lib.marl_workspace_sizes(C.byref(eng.cfg), 1, C.byref(sz_w), C.byref(sz_e)))
+        wb, eb = sz_w.value, sz_e.value  # exactly what the layout needs (the wrapper may allocate more)
+        assert wws.numel() * 4 >= wb and ews.numel() * 4 >= eb
+        assert _raw_forward(eng, g, device, wws, wb, ews, eb) == 0
+        assert _raw_forward(eng, g, device, wws, wb, ews, eb - 4) == -4
+        assert _raw_forward(eng, g, device, wws, wb - 4, ews, eb) == -4
+        assert b"workspace too small" in eng.lib.marl_last_error()
+        eng.lib.marl_tune(b"g3", 1)  # (behind the wrapper's back: buffers of the old sizes are now too small)
+        E.check(eng.lib.marl_workspace_sizes(C.byref(eng.cfg), 1, C.byref(sz_w), C.byref(sz_e)))
+        assert sz_e.value > eb and sz_w.value > wb
+        assert _raw_forward(eng, g, device, wws, wb, ews, eb) == -4
+        grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+        rc = eng.lib.marl_episode_backward(C.byref(eng.cfg), wws.data_ptr(), wb, ews.data_ptr(), eb,
+                                           g.img.to(device).data_ptr(), None, None, None, eng._table(grads), None)
+        assert rc == -4
+        rc = eng.lib.marl_a2c_loss_fwd_bwd(C.byref(eng.cfg), ews.data_ptr(), eb, *([ews.data_ptr()] * 4), C.c_float(0.9),
+                                           *([ews.data_ptr()] * 5), 0, None)
+        assert rc == -4
+        rc = eng.lib.marl_pack_weights(C.byref(eng.cfg), eng._table({k: v.to(device) for k, v in g.params.items()}),
+                                       wws.data_ptr(), wb, None)
+        assert rc == -4
+    finally:
+        E.tune("g3", 1)
+
+
+def test_gemm_nt_never_meets_a_stale_weight_image(device):
+    """the fp32 -> image registry used to outlive the episode call that filled it; a later
+    marl_gemm_nt on the same addresses then multiplied by the OLD weights' image."""
+    from marlclassification_amd import _lib
+
+    g = Golden("g2_mnist_c1")
+    eng = _engine(g, device)
+    _forward(eng, g, device)  # registers the images of every weight copy inside weights_ws
+    off, ld = C.c_int64(0), C.c_int(0)
+    idx = _lib.P["POL_W0"]
+    _lib.check(eng.lib.marl_debug_buffer(C.byref(eng.cfg), 1, f"WP{idx}".encode(), 0, C.byref(off), C.byref(ld)))
+    n, k = g.cfg.nla, g.cfg.n_a
+    w = eng.weights_ws()[off.value: off.value + n * ld.value].view(n, ld.value)
+    new = th.randn(n, k, generator=th.Generator().manual_seed(1))
+    w[:, :k] = new.to(device)  # the fp32 copy changes; the image next to it still holds the packed weights
+    a = th.randn(200, k, generator=th.Generator().manual_seed(2))
+    ad = th.zeros(200, ld.value, device=device)
+    ad[:, :k] = a.to(device)
+    cd = th.zeros(200, n, device=device)
+    _lib.check(eng.lib.marl_gemm_nt(ad.data_ptr(), ld.value, w.data_ptr(), ld.value, None, cd.data_ptr(), n, 200, n, k,
+                                    0, None))
+    assert (cd.cpu().double() - a.double() @ new.double().t()).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["g2_mnist_c1", "g4_resisc_b2"])
+def test_image_gemm_path_equals_the_fp32_operand_path(device, tag):
+    """same episode + backward with the knob g3 on (gate-gradient images, gemm3.hip products) and off: the six
+    bf16 products are the same products in both kernels, the gradients agree to rounding"""
+    from marlclassification_amd import engine as E
+
+    g = Golden(tag)
+    res = {}
+    try:
+        for mode in (0, 1):
+            E.tune("g3", mode)
+            eng = _engine(g, device)
+            out = _forward(eng, g, device)
+            gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+            grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+            eng.episode_backward(gp, gl, gv, grads)
+            res[mode] = (out, {k: v.cpu() for k, v in grads.items()})
+    finally:
+        E.tune("g3", 1)
+    assert th.equal(res[0][0].step_actions, res[1][0].step_actions)
+    worst = 0.0
+    for k in res[0][1]:
+        a, b = res[0][1][k].double(), res[1][1][k].double()
+        worst = max(worst, (a - b).abs().max().item() / max(1e-30, a.abs().max().item()))
+    assert worst <= 2e-5, worst
