@@ -18,9 +18,7 @@ class AgentOutput:
 
 
 class MultiAgent:
-    _instances = 0
-
-    def __init__(self, nb_agents: int, model: ModelsWrapper) -> None:
+    def __init__(self, nb_agents: int, model: ModelsWrapper, stream_id: int = 1) -> None:
         self.__nb_agents = nb_agents
         self.__model = model
         self.__hidden: RecurrentOutput | None = None
@@ -32,8 +30,10 @@ class MultiAgent:
         # seed and a call counter); False: torch draws the Exp(1) tensor
         self.device_rng = True
         self.__calls = 0
-        MultiAgent._instances += 1
-        self.__stream_id = MultiAgent._instances  # own generator stream (with the rank: see act)
+        # generator stream of this object's draws (mixed with torch's seed and the rank, see act).  An
+        # explicit argument, not a per-process construction counter: the draws of a run depend on the
+        # seed alone, not on how many agents a test / notebook / resume built before this one.
+        self.__stream_id = int(stream_id)
 
     def reset(self, batch_size: int) -> None:
         self.__hidden = self.__model.random_first_state(len(self), batch_size)

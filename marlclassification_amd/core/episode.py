@@ -70,9 +70,7 @@ class _EpisodeFunction(th.autograd.Function):
 
 
 class EpisodeSampler:
-    _instances = 0
-
-    def __init__(self, agents: MultiAgent, env: Environment, nb_step: int) -> None:
+    def __init__(self, agents: MultiAgent, env: Environment, nb_step: int, stream_id: int = 1) -> None:
         self.__agents = agents
         self.__env = env
         self.__nb_step = nb_step
@@ -87,9 +85,10 @@ class EpisodeSampler:
         self.__rng_seed: Optional[int] = None
         # every sampler is its own stream of the generator: the key mixes torch's seed with the
         # rank (shards draw different positions / states / noise under the usual identical
-        # th.manual_seed on all ranks) and a per-process sampler id
-        EpisodeSampler._instances += 1
-        self.__stream_id = EpisodeSampler._instances
+        # th.manual_seed on all ranks) and `stream_id` - an explicit argument, not a
+        # construction counter: same seed, same draws, whatever
+        # else the process built before
+        self.__stream_id = int(stream_id)
 
     @property
     def nb_step(self) -> int:

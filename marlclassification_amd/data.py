@@ -153,11 +153,12 @@ class ResidentLoader:
         if self.world > 1:
             import torch.distributed as dist
 
-            xs = [th.empty_like(x_loc) for _ in range(self.world)]
-            ys = [th.empty_like(y_loc) for _ in range(self.world)]
-            dist.all_gather(xs, x_loc, group=self.group)
-            dist.all_gather(ys, y_loc, group=self.group)
-            x_loc, y_loc = th.cat(xs), th.cat(ys)
+            # ONE [world * n_loc, ...] buffer filled in place: peak = (1 + 1 / world) x the image set
+            x_all = th.empty((self.world * n_loc,) + tuple(x_loc.shape[1:]), dtype=x_loc.dtype, device=self.device)
+            y_all = th.empty((self.world * n_loc,), dtype=y_loc.dtype, device=self.device)
+            dist.all_gather_into_tensor(x_all, x_loc, group=self.group)
+            dist.all_gather_into_tensor(y_all, y_loc, group=self.group)
+            x_loc, y_loc = x_all, y_all
         # indices[j] was decoded by rank j % world as its (j // world)-th image
         j = th.arange(n)
         row_of = th.full((max(self.indices) + 1,), -1, dtype=th.long)

@@ -142,7 +142,11 @@ class FusedA2C:
         read from the tensors of the capturing call (same storage every call, or re-capture).
         Outputs are persistent tensors, overwritten by every replay."""
         eng = self.engine
-        key = (img.data_ptr(), y.data_ptr(), eng._cfg_key, seed)
+        from . import engine as _engine_mod
+
+        # (the tune epoch: after engine.tune() the workspaces baked into a captured graph are freed /
+        # re-laid-out - the graph must be captured again)
+        key = (img.data_ptr(), y.data_ptr(), eng._cfg_key, seed, _engine_mod._tune_epoch)
         if self._graph is None or self._graph[0] != key:
             if self._graph is not None:
                 eng.lib.marl_graph_destroy(self._graph[1])

@@ -109,7 +109,11 @@ def resident_fits(dataset) -> bool:
     if not isinstance(dataset, ImageFolderU8) or len(dataset) == 0:
         return False
     budget = float(os.environ.get("MARL_RESIDENT_GB", "64")) * 1e9
-    return ResidentLoader.nbytes(dataset, len(dataset)) <= budget
+    # peak while the shards are exchanged: this rank's 1/world + the gathered whole (data.ResidentLoader._fill)
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return ResidentLoader.nbytes(dataset, len(dataset)) * (1.0 + (1.0 / world if world > 1 else 0.0)) <= budget
 
 
 def train_main(main_config: MainConfig, model_config: ModelConfig, train_config: TrainConfig,
@@ -139,9 +143,17 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=device)
-    # one base seed for the run (MARL_SEED, default 0): identical initial weights and data order on
-    # every rank; the episode draws mix the rank in (core/episode.py), so shards draw differently
-    base_seed = int(os.environ.get("MARL_SEED", "0"))
+    # one base seed for the run: identical initial weights and data order on every rank; the episode draws
+    # mix the rank in (core/episode.py), so shards draw differently.  MARL_SEED unset: a fresh seed per run
+    # like the reference (train.py never seeds), agreed on by all ranks; it is printed, so a run can be
+    # repeated with MARL_SEED=<that value>.
+    if "MARL_SEED" in os.environ:
+        base_seed = int(os.environ["MARL_SEED"])
+    else:
+        t = th.tensor([int.from_bytes(os.urandom(4), "little")], dtype=th.int64, device=device)
+        if distributed:
+            dist.broadcast(t, 0)
+        base_seed = int(t.item())
     th.manual_seed(base_seed)
     if rank == 0:
         print(f"seed {base_seed}, world size {world}", flush=True)
