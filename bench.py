@@ -126,7 +126,9 @@ def algorithmic_work(cfg: dict, c_img: int):
         4: 3 * (f_msg + f_pol_hidden) - f_pol_hidden,  # forward + backward dX (weight grads are class 2)
         5: 2 * f_cnn,
     }
-    return fwd, by_fwd, by_train, cls
+    # the same for a rollout (no-grad episode): only the forward products of each class run
+    cls_fwd = {0: f_lstm, 1: 2 * (n_a * nla) + 2 * (n_b * nlb + nlb * nC), 3: f_cnn, 4: f_msg + f_pol_hidden}
+    return fwd, by_fwd, by_train, cls, cls_fwd
 
 
 def cpu_baseline(budget_s: float = 25.0) -> dict:
@@ -135,7 +137,7 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
     batch-independent: SURVEY section 6).  Test infrastructure used as the measured CPU leg only."""
     from oracle import marl_oracle as mo
 
-    nb = 4
+    nb = 8
     cfg = mo.OracleConfig(C3["ft_extr"], C3["window"], C3["n_b"], C3["n_a"], C3["n_m"],
                           C3["n_m_o"], C3["n_d"], C3["nb_class"], C3["nlb"], C3["nla"])
     params = mo.init_params(cfg, 0)
@@ -145,6 +147,8 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
     v = {k: th.zeros_like(x) for k, x in params.items()}
 
     def run(faithful: bool, budget: float, max_it: int) -> tuple:
+        """mean of the timed iterations: the first is discarded, then AT LEAST three are timed (round 3 timed as
+        few as one at batch 4 and the figure moved +-12 % run to run), more while the budget lasts"""
         times = []
         t_start = time.perf_counter()
         it = 0
@@ -155,12 +159,12 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
             mo.adam_step(params, grads, m, v, it + 1, LR)
             times.append(time.perf_counter() - t0)
             it += 1
-            if it >= 2 and time.perf_counter() - t_start > budget or it >= max_it:
+            if (it >= 4 and time.perf_counter() - t_start > budget) or it >= max_it:
                 break
-        return (sum(times[1:]) / len(times[1:]) if len(times) > 1 else times[0]), len(times)
+        return sum(times[1:]) / len(times[1:]), len(times)
 
-    best, n_it = run(True, budget_s, 6)
-    best_gather, _ = run(False, 8.0, 4)  # same path with an O(f^2) index-gather crop
+    best, n_it = run(True, budget_s, 8)
+    best_gather, n_it_g = run(False, 10.0, 8)  # same path with an O(f^2) index-gather crop
     return {
         "value": nb * NA * NS / best,
         "value_gather_crop": nb * NA * NS / best_gather,
@@ -169,15 +173,27 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
         "kind": "port",
         "sample": f"{n_it} full train iterations (1st discarded) of the same config at batch {nb}, "
                   "reference-faithful mask+masked_select crop, torch-CPU fp32; value_gather_crop = "
-                  "the same with an O(f^2) index-gather crop",
+                  f"the same with an O(f^2) index-gather crop ({n_it_g} iterations, 1st discarded)",
     }
+
+
+def matrix_products_note(lib, rows: int) -> str:
+    """what the matrix kernels of THIS run do, read back from the library's knobs"""
+    if lib.marl_tune_get(b"mfma_split", 1) == 0:
+        return "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, gemm.hip): knob mfma_split = 0"
+    note = ("fp32 results from three-term bf16 splits: six bf16 MFMA products per fp32 product, fp32 accumulate "
+            "(gemm_split.hip: fp32 operands split while staged)")
+    if lib.marl_tune_get(b"g3", 1) != 0 and rows % 32 == 0:
+        note += ("; in-loop backward batch and dU on pre-split operand images staged by LDS-DMA (gemm3.hip: knob g3 = 1, "
+                 "rows per step % 32 == 0)")
+    return note
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many images in all, N / world per rank")
@@ -303,7 +319,8 @@ def main() -> None:
     # Every rank runs the extra iterations (they contain the gradient all-reduce).
     roofline = None
     cpu = None
-    f_fwd, by_fwd, by_train, cls_flops = algorithmic_work(C3, IMG[0])
+    f_fwd, by_fwd, by_train, cls_train, cls_fwd = algorithmic_work(C3, IMG[0])
+    cls_flops = cls_fwd if args.rollout_only else cls_train  # what each class computes in the timed work
     steps_per_iter_gpu = nb * NA * NS
     sweep = {}
 
@@ -315,7 +332,7 @@ def main() -> None:
         state["out"], state["scalars"] = fa.iteration(img, y, draw_episode_device(eng, rng_seed, 1 << 30))
 
     for c in CLASSES:
-        if args.rollout_only and c in (2, 5):
+        if c not in cls_flops:  # (rollout: no weight-gradient / CNN-backward launches)
             continue
         if rank == 0:
             lib.marl_profile_begin(c, 4096)
@@ -333,10 +350,7 @@ def main() -> None:
         t_hbm = bytes_iter / (PEAK_HBM_GBS * 1e9)
         dom = max(sweep, key=lambda c: sweep[c][0])
         dom_ms, dom_n = sweep[dom]
-        fwd_only = {0: 1.0, 3: 1.0}  # classes that only run in the rollout
         dom_flops = cls_flops[dom] * steps_per_iter_gpu
-        if args.rollout_only and dom not in fwd_only:
-            dom_flops /= 3.0
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # the matrix classes 0-2 run fp32 products as six bf16 MFMA products (mfma_split, default):
         # their pipe is the bf16 one, priced in fp32-equivalent FLOPs = 2.5 PF / 6; with the knob
@@ -372,16 +386,16 @@ def main() -> None:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
         # THIS round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if they cover it
         # (only if they were taken from THIS library: the file carries the sha256 of csrc/*.hip|*.h)
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if nb == 256 and is_c3 and not args.rollout_only and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
                 tj = json.load(f)
             ent = tj.get(str(dom))
             if ent and tj.get("src_sha256") == csrc_sha256():
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r03_traffic.json, sources match)"
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r04_traffic.json, sources match)"
             elif ent:
-                roofline["traffic_unit"] = ("null: profiles/r03_traffic.json was measured on other kernel "
+                roofline["traffic_unit"] = ("null: profiles/r04_traffic.json was measured on other kernel "
                                             "sources (sha256 differs)")
     if distributed:
         dist.barrier()
@@ -399,13 +413,14 @@ def main() -> None:
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": workload + "; full train iteration: rollout + A2C loss + BPTT "
-                            "backward + Adam" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                "workload": workload + ("; rollout only: one no-grad episode (EpisodeSampler.run_episode under "
+                                        "th.no_grad), no loss / backward / optimiser" if args.rollout_only else
+                                        "; full train iteration: rollout + A2C loss + BPTT backward + Adam"
+                                        + (" + RCCL grad all-reduce" if world > 1 else "")),
                 "batch_per_gpu": nb, "global_batch": nb * world,
                 "parallelism": f"dp{world}",
                 "rng": "torch" if args.torch_rng else "library (Philox4x32-10)",
-                "matrix_products": "fp32 operands, 3-term bf16 split, 6 bf16 MFMA products, fp32 accumulate "
-                                   "(gemm_split.hip; MARL_MFMA_SPLIT=0: v_mfma_f32_32x32x2_f32)",
+                "matrix_products": matrix_products_note(lib, NA * nb),
                 "launch": "hipGraph replay" if args.graph else "eager",
             },
             "roofline": roofline, "cpu_baseline": cpu,

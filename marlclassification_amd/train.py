@@ -15,7 +15,7 @@ from torch.utils.data import DataLoader, Sampler
 
 from .config import MainConfig, ModelConfig, TrainConfig
 from .core import EpisodeSampler
-from .data import DevicePrefetcher, ImageFolderU8, ResidentLoader, SyntheticImages
+from .data import DevicePrefetcher, ImageFolderU8, ResidentLoader, StripedLoader, SyntheticImages
 from .parallel import GradAllReduce
 from .training import Trainer
 
@@ -185,8 +185,8 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
         if resident:  # decoded once (1/world per rank), then batches are row gathers in HBM
             loaders.append(ResidentLoader(dataset, part, bs, device, workers=workers, rank=rank, world=world))
             continue
-        dl = DataLoader(dataset, batch_sampler=bs, num_workers=workers, pin_memory=True,
-                        persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+        # (MARL_LOADER_STRIPES DataLoaders share the workers: one collate / pin thread each, data.StripedLoader)
+        dl = StripedLoader(dataset, bs, workers, int(os.environ.get("MARL_LOADER_STRIPES", max(1, workers // 8))))
         loaders.append(DevicePrefetcher(dl, device))  # upload of batch i+1 overlaps step i
 
     sampler = EpisodeSampler(marl_m, env, main_config.step)

@@ -221,7 +221,7 @@ def test_graph_replay_survives_eager_iterations_and_lr_changes(device):
 def test_png_folder_loader_rate(device, tmp_path):
     """Trains from a generated PNG folder at 256 x 256 and measures what the loader sustains
     (images / s decoded + uploaded, one rank) next to what one training step consumes; the
-    numbers go to gpurun_out/r03_loader.json (DESIGN.md quotes them)."""
+    numbers go to gpurun_out/r04_loader.json (DESIGN.md quotes them)."""
     import numpy as np
     from PIL import Image
     from torch.utils.data import DataLoader
@@ -240,7 +240,7 @@ def test_png_folder_loader_rate(device, tmp_path):
     ds = ImageFolderU8(str(tmp_path), img_size=size)
     assert len(ds) == n_img
     rec = {}
-    for workers in (0, loader_workers(ds), min(32, (os.cpu_count() or 1) - 1)):
+    for workers in (0, loader_workers(ds), min(32, (os.cpu_count() or 1) - 1), min(96, (os.cpu_count() or 1) - 1)):
         bs = ShardedBatchSampler(range(n_img), 64, 0, 1, shuffle=True, seed=1)  # (a worker decodes whole batches)
         dl = DataLoader(ds, batch_sampler=bs, num_workers=workers, pin_memory=True,
                         persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
@@ -256,6 +256,19 @@ def test_png_folder_loader_rate(device, tmp_path):
         th.cuda.synchronize()
         rec[f"workers_{workers}"] = round(seen / (time.perf_counter() - t0), 1)
         assert seen == n_img
+    # the same workers behind several DataLoaders (one collate / pin thread each): data.StripedLoader
+    from marlclassification_amd.data import StripedLoader
+    for stripes in (2, 4, 8):
+        bs = ShardedBatchSampler(range(n_img), 64, 0, 1, shuffle=True, seed=1)
+        pf = DevicePrefetcher(StripedLoader(ds, bs, min(64, (os.cpu_count() or 1) - 1), stripes), device)
+        seen0 = [y0.clone() for _, y0 in pf]  # warm-up epoch; labels in order
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        seen = [y0.clone() for x, y0 in pf]
+        th.cuda.synchronize()
+        rec[f"striped_{stripes}x_workers_64"] = round(n_img / (time.perf_counter() - t0), 1)
+        want = [th.tensor([ds[i][1] for i in b]) for b in bs]
+        assert len(seen) == len(want) and all(th.equal(a.cpu(), b) for a, b in zip(seen, want)), "batch order"
     # decode once, keep the uint8 set in HBM: fill cost, then the per-epoch gather rate
     from marlclassification_amd.data import ResidentLoader
     bs = ShardedBatchSampler(range(n_img), 256, 0, 1, shuffle=True, seed=1)
@@ -264,7 +277,8 @@ def test_png_folder_loader_rate(device, tmp_path):
     t0 = time.perf_counter()
     first = [(x[:1].clone(), y.clone()) for x, y in rl]
     th.cuda.synchronize()
-    rec["resident_fill_img_s"] = round(n_img / (time.perf_counter() - t0), 1)
+    rec["resident_fill_img_s"] = round(n_img / (time.perf_counter() - t0), 1)  # incl. starting 32 worker processes
+    rec["resident_fill_steady_img_s"] = round(rl.fill_img_s, 1)  # from the first decoded chunk on
     t0 = time.perf_counter()
     reps = 20
     for e in range(reps):
@@ -279,7 +293,7 @@ def test_png_folder_loader_rate(device, tmp_path):
     assert th.equal(first[0][0][0].cpu(), ds[idx0[0]][0]) and first[0][1][0].item() == ds[idx0[0]][1].item()
     rec["cpu_count"] = os.cpu_count()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_loader.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r04_loader.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
     # more decode processes must not be slower than the training thread decoding alone
