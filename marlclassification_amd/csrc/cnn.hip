@@ -675,12 +675,17 @@ __device__ __forceinline__ void fwd2_layer(const CnnFwdArgs& A, float* lds, floa
                     gs[0] = mean;
                     gs[1] = rstd;
                 }
+                float av[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float zv = acc0[r];
                     if (Ly.z) Ly.z[(orow * P + r) * (int64_t)cout + ch] = zv;
-                    A.u[orow * (int64_t)A.ldu + ch * P + r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                    av[r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                    A.u[orow * (int64_t)A.ldu + ch * P + r] = av[r];
                 }
+                // (P == 4: the lane's four positions are four consecutive feature columns of U)
+                if (A.u3)
+                    img_store4(A.u3 + img_off(A.u3_row0 + orow, (ch * 4) >> 4, A.u3_steps), ch * 4, av[0], av[1], av[2], av[3]);
             }
         }
         lds_barrier();  // before the next chunk's layers overwrite the images read above
@@ -1414,6 +1419,11 @@ static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
     a.off_b1 = (int)(patch + b0);
     a.off_stat = (int)(patch + b0 + b1);
     return patch + b0 + b1 + st;
+}
+
+int cnn_fwd_writes_image(const CnnFwdArgs& a) {
+    const int w = cnn_fwd2_which(a);  // Fwd2Resisc / Fwd2Mnist6: last layer = four positions per patch (mode 1)
+    return w == 1 || w == 2;
 }
 
 int cnn_fwd_supported(const CnnFwdArgs& a0) {

@@ -386,6 +386,9 @@ struct SampleArgs {
     float* pe_stats;  // [R, 2]
     float* pe_out;    // [R, pe_ldo] (the lambda slice of U[t+1])
     int pe_ldz, pe_ldo, pe_nd;
+    // optional: the same values into the k16 image of U[t+1] (columns pe_col0 .., image row r + pe_row0)
+    char* pe_img;
+    int pe_row0, pe_steps, pe_col0;
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 
@@ -464,6 +467,10 @@ struct PanelLayer {
     float* stats;  // [M, 2] mean, rstd (nullable)
     float* a;      // SiLU(LN(z)) [M, lda]
     int lda;
+    // optional: the activations also into a k16 image (split.h): row r -> image row r + a3_row0, column
+    // c -> image column c + a3_col0 (n and a3_col0 multiples of 4)
+    char* a3;
+    int a3_row0, a3_steps, a3_col0;
 };
 constexpr int kPanelMaxLayers = 4;
 struct PanelFwdProb {
@@ -512,6 +519,9 @@ struct LstmBwdArgs {
     // GEMMs that consume them; written by the four-units-per-thread forms only (n % 4 == 0)
     char* g3;
     int g3_row0, g3_steps;
+    // 1: every consumer of the gate gradients reads the image - the fp32 copy is not written (the
+    // four-units-per-thread forms only; callers set it only where the image is certain to be written)
+    int skip_f32;
 };
 struct LstmBwdBatch {
     LstmBwdArgs a[2];
@@ -567,9 +577,11 @@ __device__ __forceinline__ void lstm_cell_bwd_at4(const LstmBwdArgs& A, int64_t 
         o[3][q] = dhv[q] * tc * go[q] * (1.0f - go[q]);
         o[4][q] = dcv * gf[q];
     }
+    if (!(A.g3 && A.skip_f32)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<float4*>(g + k * n) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4*>(g + k * n) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    }
     *reinterpret_cast<float4*>(A.dc + r * A.lddc + u) = make_float4(o[4][0], o[4][1], o[4][2], o[4][3]);
     if (A.g3) {
 #pragma unroll
@@ -691,6 +703,9 @@ struct CnnFwdArgs {
     CnnFwdLayer layer[MARL_MAX_CNN_LAYERS];
     float* u;  // [R][ldu], feature index c * P_last + pos (the reference's NCHW flatten)
     int ldu;
+    // optional (cnn_fwd2 nets whose last layer has 4 positions): the features also into the k16 image of U
+    char* u3;
+    int u3_row0, u3_steps;
     // filled by the launcher
     int rb;                       // patches per workgroup
     int off_b0, off_b1, off_stat; // LDS float offsets: even / odd layers' output, statistics
@@ -703,6 +718,7 @@ struct CnnFwdArgs {
 #endif
 };
 int cnn_fwd_supported(const CnnFwdArgs& a);
+int cnn_fwd_writes_image(const CnnFwdArgs& a);  // the launch selected for these shapes honours a.u3
 int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------

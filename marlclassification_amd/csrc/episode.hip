@@ -204,9 +204,20 @@ struct WLayout {
 // The image GEMMs (gemm3.hip) take over the large products when every step's row slice starts on an
 // image row block (R % 32 == 0: all BASELINE shapes) and the cells' widths keep 16-byte accesses.
 // (Layout-relevant: the workspaces grow by the images - marl_workspace_sizes after a knob change.)
+// Measured: a gain from cells of >= 128 units on (C3 -1.8 %, C4 -4.8 % per iteration);
+// the 64-unit MNIST shapes lose 4 % to the image writes, so they keep the fp32-operand kernels unless the
+// knob g3_min_units is lowered (the parity fixtures do that to run this path on small shapes too).
 static bool g3_enabled(const Dims& d) {
+    const int mu = tune_get("g3_min_units", 128);
     return split_mode() && tune_get("g3", 1) != 0 && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32) &&
-           (d.n_b & 3) == 0 && (d.n_a & 3) == 0;
+           (d.n_b & 3) == 0 && (d.n_a & 3) == 0 && d.n_b >= mu && d.n_a >= mu;
+}
+// the four large weight gradients on images (gemm_tn3_kernel, 256 x 256 tiles): only where that form
+// wins - >= 32768 contraction rows and <= 512 columns on the B side (at 624 columns the third, 44 %-full
+// column tile makes it 30 % slower than the fp32-operand kernel)
+static bool g3_tn_enabled(const Dims& d) {
+    return tune_get("g3_lstm", 1) != 0 && tune_get("g3_tn", 1) != 0 &&
+           (tune_get("g3_tn", 1) == 2 || (d.NR >= 32768 && d.nin <= 512 && d.n_b <= 512 && d.n_a <= 512));
 }
 
 // conv weights whose tiles are whole (16 output channels x 16-deep K steps) get a fragment-order copy
@@ -268,6 +279,8 @@ struct ELayout {
         DZPOS, BTMP, PLN[4];
     size_t DZ[MARL_MAX_CNN_LAYERS], DCOLS[MARL_MAX_CNN_LAYERS], DA[MARL_MAX_CNN_LAYERS];
     size_t GB3, GA3;  // k16 images of the gate gradients [Ns*R, 4 n] (g3 only; float offsets)
+    size_t U3, H3, HC3;  // images of U (train: every step, else one slice), H / H^ [(Ns+1) R]
+    size_t u3_stride_rows;  // image rows between the U3 slices of consecutive steps (0: one shared slice)
     bool g3;
     size_t PART, TNS, LOSS;
     size_t RED, red_floats;  // scratch of the deferred-reduction queue (sum over every use)
@@ -390,7 +403,14 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
     e.AQ1 = b.take(NR * d.ld_nlb);
     e.part_floats = e.tns_bytes = e.loss_floats = 0;
     e.g3 = g3_enabled(d);
-    e.GB3 = e.GA3 = 0;
+    e.GB3 = e.GA3 = e.U3 = e.H3 = e.HC3 = 0;
+    e.u3_stride_rows = 0;
+    if (e.g3) {
+        e.u3_stride_rows = train ? R : 0;
+        e.U3 = b.take(img_bytes((int64_t)(train ? NR : R), d.nin) / sizeof(float));
+        e.H3 = b.take(img_bytes((int64_t)(S1 * R), d.n_b) / sizeof(float));
+        e.HC3 = b.take(img_bytes((int64_t)(S1 * R), d.n_a) / sizeof(float));
+    }
     if (train && e.g3) {
         e.GB3 = b.take(img_bytes((int64_t)NR, 4 * d.n_b) / sizeof(float));
         e.GA3 = b.take(img_bytes((int64_t)NR, 4 * d.n_a) / sizeof(float));
@@ -466,6 +486,13 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_tn(4 * d.n_b, d.n_b, nr);
         upd_tn(4 * d.n_a, d.nin, nr);
         upd_tn(4 * d.n_a, d.n_a, nr);
+        if (e.g3) {  // the same four products on images (gemm_tn3_kernel) have their own split plan
+            const int tn3[4][2] = {{4 * d.n_b, d.nin}, {4 * d.n_b, d.n_b}, {4 * d.n_a, d.nin}, {4 * d.n_a, d.n_a}};
+            for (const auto& q : tn3) {
+                const size_t v = g3_tn_scratch_bytes(q[0], q[1], nr);
+                tns = v > tns ? v : tns;
+            }
+        }
         upd_tn(d.n_d, 2, nr);
         for (int l = 0; l < d.L; ++l) {
             if (e.wgrad_ok[l]) {  // per-workgroup partial slabs of the activation-based kernel
@@ -508,6 +535,8 @@ struct Ctx {
     bool defer_slabs = false;  // also the split-K / conv weight-gradient slabs (tens of MB each)
     size_t defer_small = 0;    // ... or only those of at most this many bytes (they stay in the L2)
     bool defer_this(size_t slab_bytes) const { return defer_slabs || (defer_small && slab_bytes <= defer_small); }
+    bool u3_by_producers = false;  // the kernels that write U also write its image (no separate pass)
+    int u3_row(int t) const { return (int)(e.u3_stride_rows * (size_t)t); }
 
     const char* wp3k(int i) const { return reinterpret_cast<const char*>(W + w.wp3k[i]); }
     const char* wt3k(int i) const { return reinterpret_cast<const char*>(W + w.wt3k[i]); }
@@ -531,6 +560,8 @@ struct Ctx {
 };
 
 static void register_split_images(const Dims& d, const WLayout& w, const float* W);
+static bool use_panels(const Dims& d);
+static bool use_side_stream();
 
 static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void* ews, size_t ebytes,
                     int train, void* stream, Ctx& c) {
@@ -556,6 +587,13 @@ static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void
         return MARL_EINVAL;
     }
     register_split_images(c.d, c.w, c.W);
+    // the three kernels that write U[t] (fused CNN: features; decoder panel: message columns; sampling
+    // launch: position embedding) also write its image when all of them are on the path and the column
+    // ranges keep 8-byte image pieces whole; else (and for step 0, whose embedding comes from the
+    // stand-alone kernel) one image pass over U[t] runs ahead of the LSTM launch
+    c.u3_by_producers = c.e.g3 && tune_get("g3_lstm", 1) != 0 && tune_get("g3_u3", 1) != 0 && c.e.fused_fwd &&
+                        cnn_fwd_writes_image(cnn_fwd_shape(c.d)) && use_panels(c.d) && !use_side_stream() &&
+                        ((c.d.nf | c.d.n_mo | c.d.n_d) & 3) == 0;
     return MARL_OK;
 }
 
@@ -623,6 +661,11 @@ static int step_cnn(const Ctx& c, int t, const StepIn& in) {
                                      d.K[l], d.ldk[l], c.w.wf[4 * l] ? c.W + c.w.wf[4 * l] : nullptr};
         a.u = c.at(c.e.U, t);
         a.ldu = d.ld_nin;
+        if (c.u3_by_producers) {
+            a.u3 = c.img(c.e.U3);
+            a.u3_row0 = c.u3_row(t);
+            a.u3_steps = img_steps(d.nin);
+        }
         if (c.e.fused_fwd) return launch_cnn_fwd(a, st);
     }
     if (in.obs)
@@ -668,6 +711,12 @@ static void fill_dec_layers(const Ctx& c, int t, PanelLayer* layer) {
                           c.wp(MARL_P_DEC_LN1W), c.wp(MARL_P_DEC_LN1B), d.n_mo,
                           keep ? c.at(c.e.ZD2, t) : nullptr, d.ld_nmo,
                           keep ? c.at(c.e.STD2, t) : nullptr, c.at(c.e.U, t) + d.nf, d.ld_nin};
+    if (c.u3_by_producers) {
+        layer[1].a3 = c.img(c.e.U3);
+        layer[1].a3_row0 = c.u3_row(t);
+        layer[1].a3_steps = img_steps(d.nin);
+        layer[1].a3_col0 = d.nf;
+    }
 }
 
 // message mean over the other agents + decoder -> U[t][:, nf:nf+n_mo]   (needs MSG[t])
@@ -720,6 +769,45 @@ static int step_pos_lstm(const Ctx& c, int t, const StepIn& in, bool pos_done = 
                                   c.wp(MARL_P_POS_B), c.wp(MARL_P_POS_LNW), c.wp(MARL_P_POS_LNB),
                                   c.at(c.e.NPOS, t), c.at(c.e.ZPOS, t), d.ld_nd, c.at(c.e.STPOS, t),
                                   c.at(c.e.U, t) + d.nf + d.n_mo, d.ld_nin, d.R, d.n_d, st));
+    if (c.e.g3 && tune_get("g3_lstm", 1) != 0) {
+        // image form: U[t] is complete here -> its k16 image (until its three producers write it
+        // themselves), then both cells from images; the epilogue writes the images of h' / h^'
+        const int u_row0 = c.u3_row(t);
+        if (!c.u3_by_producers || t == 0 || in.obs) {
+            ImgBatch ib{};
+            ib.d[0] = ImgDesc{c.at(c.e.U, t), c.img(c.e.U3) + img_off(u_row0, 0, img_steps(d.nin)), d.R, d.nin, d.ld_nin};
+            ib.count = 1;
+            MARL_TRY(launch_images(ib, st));
+        }
+        const int r0 = (int)((int64_t)t * d.R), r1 = r0 + R;
+        G3Batch g{};
+        g.count = 2;
+        G3Prob& qb = g.p[0];
+        qb = g3_prob(c.img(c.e.U3), u_row0, c.wp3k(MARL_P_LB_WIH), 0, d.nin, nullptr, 0, R, d.n_b, c.W + c.w.bsum_b);
+        g3_add_seg(qb, c.img(c.e.H3), r0, c.wp3k(MARL_P_LB_WHH), 0, d.n_b);
+        qb.c_prev = c.Cs(t);
+        qb.h_next = c.Hs(t + 1);
+        qb.c_next = c.Cs(t + 1);
+        qb.gates = c.train ? c.at(c.e.GB, t) : nullptr;
+        qb.ld_state = d.ld_nb;
+        qb.ld_gates = d.ld_gb;
+        qb.h3 = c.img(c.e.H3);
+        qb.h3_row0 = r1;
+        qb.h3_steps = img_steps(d.n_b);
+        G3Prob& qa = g.p[1];
+        qa = g3_prob(c.img(c.e.U3), u_row0, c.wp3k(MARL_P_LA_WIH), 0, d.nin, nullptr, 0, R, d.n_a, c.W + c.w.bsum_a);
+        g3_add_seg(qa, c.img(c.e.HC3), r0, c.wp3k(MARL_P_LA_WHH), 0, d.n_a);
+        qa.c_prev = c.CCs(t);
+        qa.h_next = c.HCs(t + 1);
+        qa.c_next = c.CCs(t + 1);
+        qa.gates = c.train ? c.at(c.e.GA, t) : nullptr;
+        qa.ld_state = d.ld_na;
+        qa.ld_gates = d.ld_ga;
+        qa.h3 = c.img(c.e.HC3);
+        qa.h3_row0 = r1;
+        qa.h3_steps = img_steps(d.n_a);
+        return launch_gemm_lstm3(g, st);
+    }
     GemmBatch b{};
     b.count = 2;
     GemmProb& pb = b.p[0];
@@ -897,6 +985,16 @@ static bool use_side_stream() {
 static int heads_batched(const Ctx& c, int t0, int64_t rows, float* values, float* preds) {
     const Dims& d = c.d;
     hipStream_t st = c.st;
+    if (c.e.g3 && tune_get("g3_lstm", 1) != 0) {  // A = the images the LSTM epilogues wrote
+        const int r1 = (int)((int64_t)(t0 + 1) * d.R);
+        G3Batch g{};
+        g.p[0] = g3_prob(c.img(c.e.HC3), r1, c.wp3k(MARL_P_CRI_W0), 0, d.n_a, c.at(c.e.ZC1), d.ld_nla, (int)rows, d.nla,
+                         c.wp(MARL_P_CRI_B0));
+        g.p[1] = g3_prob(c.img(c.e.H3), r1, c.wp3k(MARL_P_PRE_W0), 0, d.n_b, c.at(c.e.ZQ1), d.ld_nlb, (int)rows, d.nlb,
+                         c.wp(MARL_P_PRE_B0));
+        g.count = 2;
+        MARL_TRY(launch_gemm_nt3(g, st));
+    } else
     MARL_TRY(gemm2(c,
                    gemm_prob(c.HCs(t0 + 1), d.ld_na, c.wp(MARL_P_CRI_W0), d.ld_na, d.n_a,
                              c.at(c.e.ZC1), d.ld_nla, (int)rows, d.nla, c.wp(MARL_P_CRI_B0)),
@@ -994,7 +1092,15 @@ static int load_state(const Ctx& c, const float* h, const float* cc_, const floa
     // (no message: zeros, models.py:161-162 - the whole padded row)
     q.push(copy_desc(msg, d.n_m, c.MSGs(0), d.ld_nm, d.R, msg ? d.n_m : d.ld_nm));
     q.flush();
-    return q.rc;
+    MARL_TRY(q.rc);
+    if (c.e.g3) {  // the image GEMMs read the state through its images
+        ImgBatch ib{};
+        ib.d[0] = ImgDesc{h, c.img(c.e.H3), d.R, d.n_b, d.n_b};
+        ib.d[1] = ImgDesc{hc, c.img(c.e.HC3), d.R, d.n_a, d.n_a};
+        ib.count = 2;
+        MARL_TRY(launch_images(ib, c.st));
+    }
+    return MARL_OK;
 }
 
 
@@ -1103,6 +1209,29 @@ static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, in
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
                           c.e.tns_bytes, c.st, bias,
                           c.defer_this(gemm_tn_scratch_bytes(ni, nj, rows)) ? c.rq : nullptr);
+}
+// the same from images (rows = contraction index; A [rows, ni], B [rows, nj], both starting at image row 0)
+static int tn3(const Ctx& c, const char* a3, int ni, const char* b3, int nj, int pidx, int64_t rows, float* bias) {
+    const G3TnPlan plan = g3_tn_plan(ni, nj, rows);
+    if (g3_tn_scratch_bytes(ni, nj, rows) > c.e.tns_bytes) {
+        set_error("tn3: scratch too small");
+        return MARL_ESIZE;
+    }
+    float* scratch = c.at(c.e.TNS);
+    G3TnArgs a{};
+    a.a3 = a3;
+    a.b3 = b3;
+    a.a_steps = img_steps(ni);
+    a.b_steps = img_steps(nj);
+    a.out = scratch;
+    a.ldo = nj;
+    a.out_split_stride = (int64_t)ni * nj;
+    a.ni = ni;
+    a.nj = nj;
+    a.rows = rows;
+    a.csum = bias ? scratch + (size_t)plan.splits * ni * nj : nullptr;
+    MARL_TRY(launch_gemm_tn3(a, plan, c.st));
+    return launch_slab_reduce(scratch, (int64_t)ni * nj, plan.splits, c.gp(pidx), c.w.ldp[pidx], ni, nj, a.csum, bias, c.st);
 }
 // scratch for `blocks` affine partial rows of width 2n: the queue's when the reduction can wait
 static float* part_scratch(const Ctx& c, int64_t blocks, int n, int acc, RedQueue*& q) {
@@ -1251,6 +1380,8 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     bool belief_done = false;  // the belief cell: by the epilogue of the chained panel launch
     const bool chain = ride && use_chain(d);
     const bool g3 = c.e.g3;  // the gate gradients also leave as k16 images; the products below read those
+    // every consumer on images (in-loop batch, dU, the four weight gradients): no fp32 copy of them at all
+    const int skip_f32 = g3 && dl_in_loop && g3_tn_enabled(d) && tune_get("g3_skip_f32", 1) != 0;
     const int pln_blocks = chain ? panel_chain_blocks(d.na, d.nb) : panel_bwd_blocks(R);
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
@@ -1260,11 +1391,11 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
             if (!belief_done)
                 lb.a[nc++] = LstmBwdArgs{c.DHs(t + 1), c.at(c.e.DC), c.at(c.e.GB, t), c.Cs(t), c.Cs(t + 1), d.ld_nb,
                                          d.ld_nb, d.ld_gb, d.ld_nb, d.n_b, g3 ? c.img(c.e.GB3) : nullptr,
-                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_b)};
+                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_b), skip_f32};
             if (!action_done)
                 lb.a[nc++] = LstmBwdArgs{c.DHCs(t + 1), c.at(c.e.DCC), c.at(c.e.GA, t), c.CCs(t), c.CCs(t + 1), d.ld_na,
                                          d.ld_na, d.ld_ga, d.ld_na, d.n_a, g3 ? c.img(c.e.GA3) : nullptr,
-                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_a)};
+                                         (int)((int64_t)t * d.R), img_steps(4 * d.n_a), skip_f32};
             lb.rows = d.R;
             if (nc) MARL_TRY(launch_lstm_cell_bwd_batch(lb, nc, st));
         }
@@ -1360,7 +1491,8 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                 pd.has_cell = 1;
                 pd.cell = LstmBwdArgs{c.DHCs(t), c.at(c.e.DCC), c.at(c.e.GA, t - 1), c.CCs(t - 1),
                                       c.CCs(t), d.ld_na, d.ld_na, d.ld_ga, d.ld_na, d.n_a,
-                                      g3 ? c.img(c.e.GA3) : nullptr, (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_a)};
+                                      g3 ? c.img(c.e.GA3) : nullptr, (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_a),
+                                      skip_f32};
                 pd.cell_rows = d.R;
                 action_done = true;
             }
@@ -1388,7 +1520,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                     pd.has_cellb = 1;
                     pd.cellb = LstmBwdArgs{c.DHs(t), c.at(c.e.DC), c.at(c.e.GB, t - 1), c.Cs(t - 1), c.Cs(t),
                                            d.ld_nb, d.ld_nb, d.ld_gb, d.ld_nb, d.n_b, g3 ? c.img(c.e.GB3) : nullptr,
-                                           (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_b)};
+                                           (int)((int64_t)(t - 1) * d.R), img_steps(4 * d.n_b), skip_f32};
                     belief_done = true;
                 }
                 MARL_TRY(launch_panel_bwd(pd, st));
@@ -1479,10 +1611,19 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         MARL_TRY(launch_fill(c.gp(MARL_P_ENC_W0), (int64_t)d.nm2 * c.w.ldp[MARL_P_ENC_W0], 0.f, st));
         MARL_TRY(launch_fill(c.gp(MARL_P_ENC_W1), (int64_t)d.n_m * c.w.ldp[MARL_P_ENC_W1], 0.f, st));
     }
+    if (g3 && g3_tn_enabled(d)) {
+        // contraction over the rows of the images written by the cell-backward kernels (gate gradients),
+        // the forward kernels (U) and the LSTM epilogues (h, h^); bias gradients = column sums of A
+        MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.U3), d.nin, MARL_P_LB_WIH, NR, nullptr));
+        MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.H3), d.n_b, MARL_P_LB_WHH, NR, grads[MARL_P_LB_BIH]));
+        MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.U3), d.nin, MARL_P_LA_WIH, NR, nullptr));
+        MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.HC3), d.n_a, MARL_P_LA_WHH, NR, grads[MARL_P_LA_BIH]));
+    } else {
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.at(c.e.U, 0), d.ld_nin, MARL_P_LB_WIH, 4 * d.n_b, d.nin, NR));
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR, grads[MARL_P_LB_BIH]));
     MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.at(c.e.U, 0), d.ld_nin, MARL_P_LA_WIH, 4 * d.n_a, d.nin, NR));
     MARL_TRY(tn(c, c.at(c.e.GA, 0), d.ld_ga, c.HCs(0), d.ld_na, MARL_P_LA_WHH, 4 * d.n_a, d.n_a, NR, grads[MARL_P_LA_BIH]));
+    }
 
     // ---- dU for all steps, then position embedding and CNN backward -------------------
     {
@@ -1771,6 +1912,12 @@ int marl_episode_forward(const marl_config* cfg, const void* weights_ws, size_t 
             a.pe_ldz = d.ld_nd;
             a.pe_ldo = d.ld_nin;
             a.pe_nd = d.n_d;
+            if (c.u3_by_producers) {
+                a.pe_img = c.img(c.e.U3);
+                a.pe_row0 = c.u3_row(t + 1);
+                a.pe_steps = img_steps(d.nin);
+                a.pe_col0 = d.nf + d.n_mo;
+            }
         }
         // sample(t) and decoder(t+1) are independent (the decoder needs MSG[t+1], written by the
         // encoder above): one launch runs both

@@ -391,7 +391,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 
-template <int BI, int BJ, int WI, int WJ, int NST>
+// DB: fragments double-buffered in registers (step s + 1 read while step s multiplies, NST - 2 steps in
+// flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
+// fragments of step s are read right behind the barrier, NST - 1 steps in flight.
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
 __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WI * WJ;
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;  // bf16 1.0
 
-    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    bf16x8 fa0[3][TM], fb0[3][TN], fa1[DB ? 3 : 1][DB ? TM : 1], fb1[DB ? 3 : 1][DB ? TN : 1];
 #define G3T_FRAG(p0_, p1_, off_)                                                                     \
     __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p0_) + (off_))),    \
                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p1_) + (off_))), 0, 1, 2, 3, 4, 5, 6, 7)
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
         ++s;                                                                                         \
     }
 
-    if (S > 0) {
+    if (S > 0 && DB) {
 #pragma unroll
         for (int g = 0; g < NST; ++g)
             if (g < S) issue();
@@ -544,6 +547,20 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
             G3T_BODY(fa1, fb1, fa0, fb0, false)
         }
         if (s < S) G3T_BODY(fa0, fb0, fa1, fb1, false)
+    } else if (S > 0) {
+        // one fragment set: [wait step s] [barrier] [issue step s + NST - 1] [read step s] [multiply]
+#pragma unroll
+        for (int g = 0; g < NST - 1; ++g)
+            if (g < S) issue();
+        int rslot = 0;
+        for (int s = 0; s < S; ++s) {
+            if (!P.safe && gi < S) { G3T_WAIT(NST - 2) } else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (gi < S) issue();
+            G3T_LOADF(fa0, fb0, rslot)
+            G3T_MMA(fa0, fb0)
+            rslot = rslot + 1 == NST ? 0 : rslot + 1;
+        }
     }
 #undef G3T_BODY
 #undef G3T_WAIT
@@ -796,11 +813,11 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
     return rc;
 }
 
-template <int BI, int BJ, int WI, int WJ, int NST>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
 static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NST * ((BI + BJ) / 16) * 16 * kImgRowBytes;
     static_assert(lds <= 160 * 1024 && (size_t)WI * WJ * 32 * 36 * 4 <= lds, "LDS ring / epilogue panels");
-    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST>;
+    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST, DB>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -817,10 +834,11 @@ static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
 G3TnPlan g3_tn_plan(int ni, int nj, int64_t rows) {
     G3TnPlan p;
     p.variant = tune_get("g3_tn_variant", 0);
-    if (!p.variant) p.variant = 2;
-    const int bi = p.variant == 1 ? 256 : 128;
-    const int64_t tiles = cdiv(ni, bi) * cdiv(nj, 128);
-    int64_t s = cdiv(tune_get("g3_tn_wgs", p.variant == 1 ? 256 : 512), tiles);
+    // 256 x 256 tiles when both sides fill them (measured: wins from 32768 rows on with <= 2 column tiles)
+    if (!p.variant) p.variant = (ni >= 256 && nj >= 192 && nj <= 512 && rows >= 32768) ? 3 : 2;
+    const int bi = p.variant == 2 ? 128 : 256, bj = p.variant == 3 ? 256 : 128;
+    const int64_t tiles = cdiv(ni, bi) * cdiv(nj, bj);
+    int64_t s = cdiv(tune_get("g3_tn_wgs", p.variant == 2 ? 512 : 256), tiles);
     const int64_t max_s = cdiv(rows, 256);  // at least 16 stages per split
     if (s > max_s) s = max_s;
     if (s > 512) s = 512;
@@ -849,8 +867,8 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     }
     a.rows_per_split = plan.rows_per_split;
     a.safe = tune_get("g3_safe", 0) != 0;
-    const int bi = plan.variant == 1 ? 256 : 128;
-    dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)cdiv(a.nj, 128), (unsigned)plan.splits);
+    const int bi = plan.variant == 2 ? 128 : 256, bj = plan.variant == 3 ? 256 : 128;
+    dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)cdiv(a.nj, bj), (unsigned)plan.splits);
     a.gx = a.gy = a.gz = 0;
     if (tune_get("tn_xcd", 1)) {
         a.gx = (int)grid.x;
@@ -861,9 +879,11 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     prof_before(2, st);
     int rc;
     if (plan.variant == 1)
-        rc = launch_tn3_variant<256, 128, 4, 2, 4>(a, grid, st);
+        rc = launch_tn3_variant<256, 128, 4, 2, 4, true>(a, grid, st);
+    else if (plan.variant == 3)
+        rc = launch_tn3_variant<256, 256, 4, 2, 3, false>(a, grid, st);
     else
-        rc = launch_tn3_variant<128, 128, 2, 2, 3>(a, grid, st);
+        rc = launch_tn3_variant<128, 128, 2, 2, 3, true>(a, grid, st);
     prof_after(2, st);
     return rc;
 }

@@ -406,6 +406,15 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
                         Lr.stats[(size_t)row * 2] = mean;
                         Lr.stats[(size_t)row * 2 + 1] = rstd;
                     }
+                    if (Lr.a3 && row >= 0) {
+                        // the row's activations are in the LDS panel (written by this wave just above): four
+                        // consecutive columns per lane -> 8-byte pieces of the three image planes
+                        for (int c4 = 4 * lane; c4 < n; c4 += 256) {
+                            const float4 t = *reinterpret_cast<const float4*>(zr + c4);
+                            const int col = Lr.a3_col0 + c4;
+                            img_store4(Lr.a3 + img_off((int64_t)Lr.a3_row0 + row, col >> 4, Lr.a3_steps), col, t.x, t.y, t.z, t.w);
+                        }
+                    }
                 }
             }
         }
@@ -886,11 +895,13 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                             o3[q] = tot[q] * tc * go_[q] * (1.0f - go_[q]);
                             o4[q] = d * gf_[q];
                         }
-                        float* g = Cb.gates + (size_t)rowi[k] * Cb.ldg + coli[k];
-                        *reinterpret_cast<float4*>(g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-                        *reinterpret_cast<float4*>(g + cn) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-                        *reinterpret_cast<float4*>(g + 2 * cn) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-                        *reinterpret_cast<float4*>(g + 3 * cn) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+                        if (!(Cb.g3 && Cb.skip_f32)) {
+                            float* g = Cb.gates + (size_t)rowi[k] * Cb.ldg + coli[k];
+                            *reinterpret_cast<float4*>(g) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+                            *reinterpret_cast<float4*>(g + cn) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+                            *reinterpret_cast<float4*>(g + 2 * cn) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                            *reinterpret_cast<float4*>(g + 3 * cn) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+                        }
                         *reinterpret_cast<float4*>(Cb.dc + (size_t)rowi[k] * Cb.lddc + coli[k]) =
                             make_float4(o4[0], o4[1], o4[2], o4[3]);
                         if (Cb.g3) {  // the k16 image of the gate gradients (A operand of the image GEMMs)
@@ -977,6 +988,8 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     p.cellb_img_done = p.has_cellb && p.cellb.g3 && tail_lds;
     p.cell_vec4 = p.has_cell && lstm_bwd_vec4_ok(p.cell);
     p.cell_img_done = p.has_cell && p.cell.g3 && p.cell_vec4;
+    if (!p.cellb_img_done) p.cellb.skip_f32 = 0;  // (the fallback builds the image from the fp32 gradients)
+    if (!p.cell_img_done) p.cell.skip_f32 = 0;
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
         const unsigned cblocks = (unsigned)cdiv(p.cell_rows * (p.cell_vec4 ? p.cell.n / 4 : p.cell.n), 64 * waves);

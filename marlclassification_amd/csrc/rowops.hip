@@ -1142,7 +1142,7 @@ int launch_lstm_cell_bwd(const float* dh, int lddh, float* dc, int lddc, float* 
                          const float* c_prev, const float* c_new, int ldc, int64_t rows, int n,
                          hipStream_t st) {
     LstmBwdBatch b{};
-    b.a[0] = LstmBwdArgs{dh, dc, gates, c_prev, c_new, lddh, lddc, ldg, ldc, n, nullptr, 0, 0};
+    b.a[0] = LstmBwdArgs{dh, dc, gates, c_prev, c_new, lddh, lddc, ldg, ldc, n, nullptr, 0, 0, 0};
     b.rows = rows;
     return launch_lstm_cell_bwd_batch(b, 1, st);
 }
@@ -1154,8 +1154,8 @@ int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, fl
                           int ldg1, const float* cp1, const float* cn1, int ldc1, int n1,
                           int64_t rows, hipStream_t st) {
     LstmBwdBatch b{};
-    b.a[0] = LstmBwdArgs{dh0, dc0, gates0, cp0, cn0, lddh0, lddc0, ldg0, ldc0, n0, nullptr, 0, 0};
-    b.a[1] = LstmBwdArgs{dh1, dc1, gates1, cp1, cn1, lddh1, lddc1, ldg1, ldc1, n1, nullptr, 0, 0};
+    b.a[0] = LstmBwdArgs{dh0, dc0, gates0, cp0, cn0, lddh0, lddc0, ldg0, ldc0, n0, nullptr, 0, 0, 0};
+    b.a[1] = LstmBwdArgs{dh1, dc1, gates1, cp1, cn1, lddh1, lddc1, ldg1, ldc1, n1, nullptr, 0, 0, 0};
     b.rows = rows;
     return launch_lstm_cell_bwd_batch(b, 2, st);
 }

@@ -198,6 +198,19 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
             const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
             A.pe_out[(size_t)r * A.pe_ldo + j] = sample_silu((v - mean) * rstd * A.pe_gamma[j] + A.pe_beta[j]);
         }
+        if (A.pe_img) {  // the same values, four consecutive columns per lane, into the image of U[t+1]
+            for (int j4 = 4 * lane; j4 < nd; j4 += 256) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = j4 + q;
+                    const float v = A.pe_b[j] + p0 * A.pe_W[4 * j] + p1 * A.pe_W[4 * j + 1];
+                    o[q] = sample_silu((v - mean) * rstd * A.pe_gamma[j] + A.pe_beta[j]);
+                }
+                const int col = A.pe_col0 + j4;
+                img_store4(A.pe_img + img_off((int64_t)A.pe_row0 + r, col >> 4, A.pe_steps), col, o[0], o[1], o[2], o[3]);
+            }
+        }
     }
 }
 

@@ -43,7 +43,7 @@ def test_workspace_sizes_are_checked_by_the_abi(device):
     """a buffer sized before a layout knob changed is refused with MARL_ESIZE (-4)"""
     from marlclassification_amd import engine as E
 
-    g = Golden("g4_resisc_b2")  # R = 32: the image-GEMM layout (knob g3) adds the gate-gradient images
+    g = Golden("g4_resisc_b2")  # R = 32: the image-GEMM layout (knob g3) adds the operand images
     try:
         E.tune("g3", 0)
         eng = _engine(g, device)
@@ -98,6 +98,53 @@ def test_gemm_nt_never_meets_a_stale_weight_image(device):
     assert (cd.cpu().double() - a.double() @ new.double().t()).abs().max().item() < 1e-4
 
 
+class image_path:
+    """forces the image-GEMM path (csrc/gemm3.hip: LSTM, in-loop batch, heads, dU, the four large weight gradients
+    incl. the 256 x 256 row-contraction kernel) on shapes whose defaults keep the fp32-operand kernels"""
+
+    KNOBS = (("g3", 1), ("g3_min_units", 1), ("g3_tn", 2))
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        from marlclassification_amd import engine as E
+
+        for k, v in self.KNOBS:
+            E.tune(k, v if self.on else 0 if k == "g3" else v)
+
+    def __exit__(self, *exc):
+        from marlclassification_amd import engine as E
+
+        E.tune("g3", 1)
+        E.tune("g3_min_units", 128)
+        E.tune("g3_tn", 1)
+
+
+def test_reference_parity_on_the_forced_image_path(device):
+    """the reference-golden checks of tests/test_gpu_episode.py with every large product on images: G2 (MNIST
+    C1, R = 96) and G4 (RESISC45 dims, R = 32) - bit-exact positions / actions, logits 1e-5, gradients 1e-4,
+    Adam 1e-3 lr.  (The default knobs switch this path on from 128-unit cells / 32768 rows: the benched-size
+    tests of rounds 2 and 3 run it as shipped.)"""
+    from marlclassification_amd import _lib
+    from tests import test_gpu_episode as E0
+
+    with image_path():
+        g = Golden("g2_mnist_c1")
+        eng = _engine(g, device)
+        sz = [C.c_size_t(0) for _ in range(4)]
+        _lib.check(eng.lib.marl_workspace_sizes(C.byref(eng.cfg), 1, C.byref(sz[0]), C.byref(sz[1])))
+        eng.lib.marl_tune(b"g3", 0)
+        _lib.check(eng.lib.marl_workspace_sizes(C.byref(eng.cfg), 1, C.byref(sz[2]), C.byref(sz[3])))
+        eng.lib.marl_tune(b"g3", 1)
+        assert sz[0].value > sz[2].value and sz[1].value > sz[3].value, "image layout not selected"
+        for train in (True, False):
+            E0.test_rollout_matches_reference(device, "g2_mnist_c1", train)
+        E0.test_backward_and_adam_match_reference(device, "g2_mnist_c1")
+        E0.test_loss_and_output_gradients(device, "g2_mnist_c1")
+        E0.test_backward_resisc_dims_gradient_samples(device)
+
+
 @pytest.mark.parametrize("tag", ["g2_mnist_c1", "g4_resisc_b2"])
 def test_image_gemm_path_equals_the_fp32_operand_path(device, tag):
     """same episode + backward with the knob g3 on (gate-gradient images, gemm3.hip products) and off: the six
@@ -108,7 +155,7 @@ def test_image_gemm_path_equals_the_fp32_operand_path(device, tag):
     res = {}
     try:
         for mode in (0, 1):
-            E.tune("g3", mode)
+            image_path(bool(mode)).__enter__()
             eng = _engine(g, device)
             out = _forward(eng, g, device)
             gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
@@ -116,7 +163,7 @@ def test_image_gemm_path_equals_the_fp32_operand_path(device, tag):
             eng.episode_backward(gp, gl, gv, grads)
             res[mode] = (out, {k: v.cpu() for k, v in grads.items()})
     finally:
-        E.tune("g3", 1)
+        image_path().__exit__()
     assert th.equal(res[0][0].step_actions, res[1][0].step_actions)
     worst = 0.0
     for k in res[0][1]:

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from g3_lab import image, padded, timeit, p4, lib, check, dev  # noqa
 
 rows_out = []
-for r, ni, nj in ((65536, 1024, 368), (65536, 1024, 256), (65536, 384, 256), (65536, 128, 256), (2048, 96, 80), (4096, 45, 384)):
+import sys as _s
+SHAPES = ((65536, 1024, 624), (8192, 1024, 624), (8192, 1024, 256), (49152, 256, 96)) if len(_s.argv) > 1 else ((65536, 1024, 368), (65536, 1024, 256), (65536, 384, 256), (65536, 128, 256), (2048, 96, 80), (4096, 45, 384))
+for r, ni, nj in SHAPES:
     g = th.Generator().manual_seed(r + ni + nj)
     a = th.randn(r, ni, generator=g)
     b = th.randn(r, nj, generator=g)
@@ -19,7 +21,7 @@ for r, ni, nj in ((65536, 1024, 368), (65536, 1024, 256), (65536, 384, 256), (65
     us0 = timeit(lambda: check(lib.marl_gemm_tn(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1], cd.data_ptr(), cd.shape[1], ni, nj, r, scratch.data_ptr(), sb, None)))
     err0 = (cd[:, :nj].cpu().double() - ref).abs().max().item()
     a3, b3 = image(ad, ni), image(bd, nj)
-    for variant in (2, 1):
+    for variant in (2, 1, 3):
         check(lib.marl_tune(b"g3_tn_variant", variant))
         c1 = th.full((ni, p4(nj)), 7.0, device=dev)
         cs = th.zeros(ni, device=dev)
