@@ -249,9 +249,42 @@ struct RedQueue;
 size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows);
 // colsum_out (nullable): also writes out[i] = sum_r A[r,i] (the matching bias gradient)
 // q != null: the slab reduction is queued there instead of launched (scratch comes from q too)
+struct TnQueue;
+// tq != null (needs q): a product on the 64 x 64 plan is queued there instead of launched
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
                    int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
-                   float* colsum_out = nullptr, RedQueue* q = nullptr);
+                   float* colsum_out = nullptr, RedQueue* q = nullptr, TnQueue* tq = nullptr);
+
+// Small row contractions (output of at most a few 64 x 64 tiles) of a backward pass collected and run as
+// ONE launch at its end: alone each fills a fraction of the chip for 10-50 us (gemm_tn_batch_kernel).
+struct TnBatchProb {
+    const float* a;
+    const float* b;
+    float* out;
+    float* csum;
+    int64_t stride, rows, rows_per_split;
+    int lda, ldb, ldo, ni, nj, gx, gy, first_block;
+};
+constexpr int kMaxTnBatch = 12;
+struct TnBatch {
+    TnBatchProb p[kMaxTnBatch];
+    int count;
+};
+struct TnQueue {
+    struct Item {
+        const float* a;
+        const float* b;
+        float* c;
+        float* colsum;
+        int lda, ldb, ldc, ni, nj;
+        int64_t rows;
+    };
+    Item it[kMaxTnBatch];
+    int n = 0;
+};
+bool gemm_tn_is_small(int ni, int nj, int64_t rows);  // takes the 64 x 64 plan
+// launches what is queued; the split slabs live in q's scratch and their reductions are queued there
+int launch_tn_queue(TnQueue& tq, RedQueue* q, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // Deferred fixed-order reductions (gemm.hip).  The backward pass produces ~40 sets of partial

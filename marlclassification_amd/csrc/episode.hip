@@ -532,6 +532,7 @@ struct Ctx {
     hipStream_t st;
     int train;
     RedQueue* rq = nullptr;  // backward: deferred reductions (null: every reduction launches at once)
+    TnQueue* tq = nullptr;   // backward: small weight gradients collected for one launch (needs rq)
     bool defer_slabs = false;  // also the split-K / conv weight-gradient slabs (tens of MB each)
     size_t defer_small = 0;    // ... or only those of at most this many bytes (they stay in the L2)
     bool defer_this(size_t slab_bytes) const { return defer_slabs || (defer_small && slab_bytes <= defer_small); }
@@ -1206,9 +1207,9 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
 // weight gradient gp(pidx) = A^T B over `rows` rows; bias (nullable) = column sums of A
 static int tn(const Ctx& c, const float* a, int lda, const float* b, int ldb, int pidx, int ni,
               int nj, int64_t rows, float* bias = nullptr) {
+    RedQueue* q = c.defer_this(gemm_tn_scratch_bytes(ni, nj, rows)) ? c.rq : nullptr;
     return launch_gemm_tn(a, lda, b, ldb, c.gp(pidx), c.w.ldp[pidx], ni, nj, rows, c.at(c.e.TNS),
-                          c.e.tns_bytes, c.st, bias,
-                          c.defer_this(gemm_tn_scratch_bytes(ni, nj, rows)) ? c.rq : nullptr);
+                          c.e.tns_bytes, c.st, bias, q, q ? c.tq : nullptr);
 }
 // the same from images (rows = contraction index; A [rows, ni], B [rows, nj], both starting at image row 0)
 static int tn3(const Ctx& c, const char* a3, int ni, const char* b3, int nj, int pidx, int64_t rows, float* bias) {
@@ -1295,7 +1296,9 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     // each (8 MB: larger thresholds lose again at C4) - on small problems (C2: 22 weight gradients) one batched
     // reduction replaces 22 launches: 0.953 -> 0.897 ms per iteration.
     const int defer = tune_get("red_defer", 3);
+    TnQueue tq;
     if (defer) c.rq = &rq;
+    if (defer) c.tq = &tq;
     c.defer_slabs = defer == 2;
     c.defer_small = defer == 3 ? (size_t)tune_get("red_defer_kb", 8192) * 1024 : 0;
     const Dims& d = c.d;
@@ -1370,7 +1373,11 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     const bool panels = use_panels(d) && d.n_mo <= 384 && d.nm2 <= 384 && d.n_m <= 384;
     // the per-step LayerNorm reductions of the unfused path accumulate into the gradients step
     // by step: nothing of a parameter may still be queued then, so that path does not defer
-    if (!panels) c.rq = nullptr;
+    if (!panels) {
+        MARL_TRY(launch_tn_queue(tq, c.rq, st));  // (what the heads queued so far)
+        c.rq = nullptr;
+        c.tq = nullptr;
+    }
     // The action cell's backward of step t-1 only needs dh^_t, which is complete after step t's
     // W_hh product; it rides along (extra workgroups) with step t's decoder-panel launch, so
     // that from the second iteration on only the belief cell is left for the separate launch.
@@ -1734,6 +1741,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
             }
         }
     }
+    if (c.tq) MARL_TRY(launch_tn_queue(tq, c.rq, st));  // the small weight gradients, one launch
     MARL_TRY(rq.flush());
     return unpack_grads(c, grads);
 }

@@ -399,13 +399,13 @@ __global__ __launch_bounds__(256 * GROUPS) void gemm_nt_kernel(const GemmBatch b
 // fragments are ds_read_b32 with consecutive lanes on consecutive columns.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int BK, int NBUF = 2>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
-                                                      const float* __restrict__ B, int ldb,
-                                                      float* __restrict__ out, int ldo,
-                                                      int64_t out_split_stride, int NI, int NJ,
-                                                      int64_t rows, int64_t rows_per_split,
-                                                      float* __restrict__ csum, int gx, int gy,
-                                                      int gz, int prio) {
+__device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, int lda,
+                                             const float* __restrict__ B, int ldb,
+                                             float* __restrict__ out, int ldo,
+                                             int64_t out_split_stride, int NI, int NJ,
+                                             int64_t rows, int64_t rows_per_split,
+                                             float* __restrict__ csum, int prio, unsigned bx, unsigned by,
+                                             unsigned bz) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_CH = BK * (BM / 4) / 256;
@@ -413,10 +413,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BK * (BM + BN)]
 
-    // gx > 0: 1-D launch, XCD-aware order (the tiles of one row slab run on one XCD, so its A
-    // and B row panels come from that XCD's L2 for all but the first tile)
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (gx > 0) xcd_tile(gx, gy, gz, bx, by, bz);
     const int i0 = bx * BM;
     const int j0 = by * BN;
     const int64_t r_begin = (int64_t)bz * rows_per_split;
@@ -589,6 +585,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 if (row < NI) o[(size_t)row * ldo + col] = acc[i][j][r];
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int NBUF = 2>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ B, int ldb,
+                                                      float* __restrict__ out, int ldo,
+                                                      int64_t out_split_stride, int NI, int NJ,
+                                                      int64_t rows, int64_t rows_per_split,
+                                                      float* __restrict__ csum, int gx, int gy,
+                                                      int gz, int prio) {
+    // gx > 0: 1-D launch, XCD-aware order (the tiles of one row slab run on one XCD, so its A
+    // and B row panels come from that XCD's L2 for all but the first tile)
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (gx > 0) xcd_tile(gx, gy, gz, bx, by, bz);
+    gemm_tn_body<BM, BN, WM, WN, BK, NBUF>(A, lda, B, ldb, out, ldo, out_split_stride, NI, NJ, rows, rows_per_split,
+                                           csum, prio, bx, by, bz);
+}
+
+// Several SMALL row contractions in one launch (the ~8 weight gradients of an iteration whose output
+// is at most a few 64 x 64 tiles: each alone fills a fraction of the chip for 10-50 us).  Workgroup
+// b belongs to the problem whose [first, first + tiles * splits) range holds it.
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnBatch T) {
+    int pi = 0;
+    while (pi + 1 < T.count && (int)blockIdx.x >= T.p[pi + 1].first_block) ++pi;
+    const TnBatchProb& P = T.p[pi];
+    const unsigned local = blockIdx.x - (unsigned)P.first_block;
+    const unsigned per = (unsigned)(P.gx * P.gy);
+    const unsigned bz = local / per, r = local - bz * per;
+    gemm_tn_body<64, 64, 2, 2, 32, 2>(P.a, P.lda, P.b, P.ldb, P.out, P.ldo, P.stride, P.ni, P.nj, P.rows, P.rows_per_split,
+                                      P.csum, 0, r / (unsigned)P.gy, r % (unsigned)P.gy, bz);
 }
 
 // Fixed-order reduction of partial slabs: out[e] = sum_z part[z * stride + e].  A 1024-thread
@@ -1095,9 +1121,72 @@ size_t gemm_tn_scratch_bytes(int ni, int nj, int64_t rows) {
     return p.splits > 1 ? ((size_t)p.splits * ni * nj + (size_t)p.splits * ni) * sizeof(float) : 0;
 }
 
+bool gemm_tn_is_small(int ni, int nj, int64_t rows) { return tn_plan(ni, nj, rows).bm == 64; }
+
+int launch_tn_queue(TnQueue& tq, RedQueue* q, hipStream_t st) {
+    if (tq.n == 0) return MARL_OK;
+    if (!q) return MARL_EINVAL;
+    // all slabs must come out of the scratch in one piece of time: no flush between the takes
+    size_t need = 0;
+    for (int i = 0; i < tq.n; ++i)
+        need += (gemm_tn_scratch_bytes(tq.it[i].ni, tq.it[i].nj, tq.it[i].rows) / sizeof(float) + 63) & ~(size_t)63;
+    if (q->off + need > q->cap) MARL_TRY(q->flush());
+    TnBatch tb{};
+    float* scr[kMaxTnBatch];
+    TnPlan plan[kMaxTnBatch];
+    int blocks = 0;
+    for (int i = 0; i < tq.n; ++i) {
+        const TnQueue::Item& it = tq.it[i];
+        plan[i] = tn_plan(it.ni, it.nj, it.rows);
+        scr[i] = nullptr;
+        TnBatchProb& P = tb.p[i];
+        P.a = it.a;
+        P.b = it.b;
+        P.lda = it.lda;
+        P.ldb = it.ldb;
+        P.ni = it.ni;
+        P.nj = it.nj;
+        P.rows = it.rows;
+        P.rows_per_split = plan[i].rows_per_split;
+        P.gx = (int)cdiv(it.ni, 64);
+        P.gy = (int)cdiv(it.nj, 64);
+        P.first_block = blocks;
+        blocks += P.gx * P.gy * plan[i].splits;
+        if (plan[i].splits > 1) {
+            scr[i] = q->take(gemm_tn_scratch_bytes(it.ni, it.nj, it.rows) / sizeof(float), false);
+            if (!scr[i]) {
+                set_error("tn queue: reduction scratch too small");
+                return MARL_ESIZE;
+            }
+            P.out = scr[i];
+            P.ldo = it.nj;
+            P.stride = (int64_t)it.ni * it.nj;
+            P.csum = it.colsum ? scr[i] + (size_t)plan[i].splits * it.ni * it.nj : nullptr;
+        } else {
+            P.out = it.c;
+            P.ldo = it.ldc;
+            P.stride = 0;
+            P.csum = it.colsum;
+        }
+    }
+    tb.count = tq.n;
+    prof_before(2, st);
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3((unsigned)blocks), dim3(256), (size_t)2 * 32 * 2 * 64 * sizeof(float), st, tb);
+    prof_after(2, st);
+    MARL_LAUNCH_CHECK();
+    for (int i = 0; i < tq.n; ++i) {
+        const TnQueue::Item& it = tq.it[i];
+        if (plan[i].splits <= 1) continue;
+        q->push(scr[i], (int64_t)it.ni * it.nj, plan[i].splits, it.ni * it.nj, it.c, it.ni * it.nj, it.nj, it.ldc, nullptr, 0);
+        if (it.colsum) q->push(tb.p[i].csum, it.ni, plan[i].splits, it.ni, it.colsum, it.ni, it.ni, it.ni, nullptr, 0);
+    }
+    tq.n = 0;
+    return q->rc;
+}
+
 int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int ni,
                    int nj, int64_t rows, float* scratch, size_t scratch_bytes, hipStream_t st,
-                   float* colsum_out, RedQueue* q) {
+                   float* colsum_out, RedQueue* q, TnQueue* tq) {
     if (!a || !b || !c || ni <= 0 || nj <= 0 || rows <= 0 || (lda & 3) || (ldb & 3) ||
         lda < p4(ni) || ldb < p4(nj) || (reinterpret_cast<uintptr_t>(a) & 15) ||
         (reinterpret_cast<uintptr_t>(b) & 15)) {
@@ -1106,6 +1195,11 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         return MARL_EINVAL;
     }
     TnPlan p = tn_plan(ni, nj, rows);
+    if (tq && q && p.bm == 64 && tune_get("tn_batch", 1) != 0) {  // small product: runs with the others, later
+        if (tq->n == kMaxTnBatch) MARL_TRY(launch_tn_queue(*tq, q, st));
+        tq->it[tq->n++] = TnQueue::Item{a, b, c, colsum_out, lda, ldb, ldc, ni, nj, rows};
+        return MARL_OK;
+    }
     float* out = c;
     int ldo = ldc;
     int64_t stride = 0;

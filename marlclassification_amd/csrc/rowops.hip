@@ -30,12 +30,13 @@ struct Knob {
     int value;
     bool set;
 };
-Knob g_knobs[32];
+constexpr int kMaxKnobs = 128;
+Knob g_knobs[kMaxKnobs];
 int g_nknobs = 0;
 Knob* knob(const char* key, bool create) {
     for (int i = 0; i < g_nknobs; ++i)
         if (!strcmp(g_knobs[i].key, key)) return &g_knobs[i];
-    if (!create || g_nknobs >= 32 || strlen(key) >= sizeof(g_knobs[0].key)) return nullptr;
+    if (!create || g_nknobs >= kMaxKnobs || strlen(key) >= sizeof(g_knobs[0].key)) return nullptr;
     Knob* k = &g_knobs[g_nknobs++];
     strcpy(k->key, key);
     k->value = 0;
@@ -46,7 +47,10 @@ Knob* knob(const char* key, bool create) {
 
 int tune_set(const char* key, int value) {
     Knob* k = knob(key, true);
-    if (!k) return MARL_EINVAL;
+    if (!k) {
+        set_error("marl_tune: knob table full or key too long (%s)", key);
+        return MARL_EINVAL;
+    }
     k->value = value;
     k->set = true;
     return MARL_OK;
