@@ -3,7 +3,7 @@ launch of every kernel class of marl_profile_begin, = 2 x FETCH_SIZE (gfx950 cor
 coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KB.  The file is
 stamped with the sha256 of csrc/*.hip|*.h at profiling time; bench.py only quotes it while the
 sources it runs still hash to that value.
-usage: python tools/make_traffic_json.py r03"""
+usage: python tools/make_traffic_json.py r04"""
 import csv
 import json
 import os
@@ -13,7 +13,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from bench import csrc_sha256  # noqa: E402
 
 rnd = sys.argv[1]
-CLASS_OF = [("gemm_nt_kernel<128, 128, 4, 1, true", 0), ("gemm_nt_split_kernel<128, true", 0),
+CLASS_OF = [("gemm_nt3_kernel<128, 128, 4, 1, 3, true", 0), ("gemm_nt3_kernel<256, 128, 8, 1, 4, true", 0),
+            ("gemm_nt3_kernel", 1), ("gemm_tn3_kernel", 2), ("gemm_tn_batch_kernel", 2),
+            ("gemm_nt_kernel<128, 128, 4, 1, true", 0), ("gemm_nt_split_kernel<128, true", 0),
             ("gemm_nt_kernel", 1), ("gemm_nt_split_kernel", 1), ("gemm_tn_kernel", 2),
             ("gemm_tn_split_kernel", 2), ("cnn_fwd", 3), ("panel_", 4), ("cnn_dgrad", 5), ("cnn_wgrad", 5),
             ("cnn_bwd", 5)]
@@ -44,7 +46,8 @@ tot_f = sum(c * f for c, f in F.values())
 tot_w = sum(c * W[k][1] for k, (c, _) in F.items() if k in W)
 out["whole_run_2xfetch_plus_write_gb"] = round((2 * tot_f + tot_w) * 1024 / 1e9, 3)
 # iterations in the profiled command: 1 warm-up + 2 timed + one per kernel class of the sweep
-lstm = next((c for k, (c, _) in F.items() if k.startswith(("gemm_nt_split_kernel<128, true", "gemm_nt_kernel<128, 128, 4, 1, true"))), 0)
+lstm = next((c for k, (c, _) in F.items() if k.startswith(("gemm_nt3_kernel<128, 128, 4, 1, 3, true", "gemm_nt_split_kernel<128, true",
+                                                            "gemm_nt_kernel<128, 128, 4, 1, true"))), 0)
 out["whole_run_iterations"] = lstm // 16 if lstm else None  # (the LSTM kernel runs once per step, 16 steps)
 if lstm:
     out["per_iteration_2xfetch_plus_write_gb"] = round(out["whole_run_2xfetch_plus_write_gb"] / (lstm // 16), 3)
