@@ -183,9 +183,9 @@ def matrix_products_note(lib, rows: int) -> str:
         return "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, gemm.hip): knob mfma_split = 0"
     note = ("fp32 results from three-term bf16 splits: six bf16 MFMA products per fp32 product, fp32 accumulate "
             "(gemm_split.hip: fp32 operands split while staged)")
-    if lib.marl_tune_get(b"g3", 1) != 0 and rows % 32 == 0:
-        note += ("; in-loop backward batch and dU on pre-split operand images staged by LDS-DMA (gemm3.hip: knob g3 = 1, "
-                 "rows per step % 32 == 0)")
+    if lib.marl_tune_get(b"g3", 1) != 0 and rows % 32 == 0 and min(C3["n_b"], C3["n_a"]) >= lib.marl_tune_get(b"g3_min_units", 128):
+        note += ("; LSTM cells, in-loop backward batch, batched heads, dU and the four large weight gradients on operand "
+                 "images pre-split by their producers and staged by LDS-DMA (gemm3.hip: knob g3 = 1)")
     return note
 
 
