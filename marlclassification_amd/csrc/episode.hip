@@ -212,12 +212,12 @@ static bool g3_enabled(const Dims& d) {
     return split_mode() && tune_get("g3", 1) != 0 && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32) &&
            (d.n_b & 3) == 0 && (d.n_a & 3) == 0 && d.n_b >= mu && d.n_a >= mu;
 }
-// the four large weight gradients on images (gemm_tn3_kernel, 256 x 256 tiles): only where that form
-// wins - >= 32768 contraction rows and <= 512 columns on the B side (at 624 columns the third, 44 %-full
-// column tile makes it 30 % slower than the fp32-operand kernel)
+// the four large weight gradients on images (gemm_tn3_kernel: 256-column tiles of A, whole 256 x 256 tiles
+// or column passes, g3_tn_plan): only where that form wins - >= 32768 contraction rows (at C4's 8192 rows the
+// fp32-operand kernel is 25 % faster) and at most three column passes on the B side
 static bool g3_tn_enabled(const Dims& d) {
     return tune_get("g3_lstm", 1) != 0 && tune_get("g3_tn", 1) != 0 &&
-           (tune_get("g3_tn", 1) == 2 || (d.NR >= 32768 && d.nin <= 512 && d.n_b <= 512 && d.n_a <= 512));
+           (tune_get("g3_tn", 1) == 2 || (d.NR >= 32768 && d.nin <= 640 && d.n_b <= 512 && d.n_a <= 512));
 }
 
 // conv weights whose tiles are whole (16 output channels x 16-deep K steps) get a fragment-order copy

@@ -395,7 +395,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 // flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
 // fragments of step s are read right behind the barrier, NST - 1 steps in flight.
 template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
-__global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
+__device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsigned bx, int j0, unsigned bz, bool first_col_tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WI * WJ;
     constexpr int TM = BI / WI / 32, TN = BJ / WJ / 32;
@@ -407,10 +407,7 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
     constexpr int I_EXTRA = T_INS % NW;
     constexpr int NF = 6 * (TM + TN), NMMA = 6 * TM * TN;
 
-    extern __shared__ __attribute__((aligned(16))) char sm[];
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (P.gx > 0) xcd_tile(P.gx, P.gy, P.gz, bx, by, bz);
-    const int i0 = bx * BI, j0 = by * BJ;
+    const int i0 = bx * BI;
     const int64_t r_begin = (int64_t)bz * P.rows_per_split;
     int64_t r_end = r_begin + P.rows_per_split;
     if (r_end > P.rows) r_end = P.rows;
@@ -478,7 +475,7 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    const bool do_csum = P.csum != nullptr && by == 0;
+    const bool do_csum = P.csum != nullptr && first_col_tile;
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;  // bf16 1.0
@@ -615,6 +612,31 @@ __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs
         }
     }
 #endif
+}
+
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
+__global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (P.gx > 0) xcd_tile(P.gx, P.gy, P.gz, bx, by, bz);
+    gemm_tn3_body<BI, BJ, WI, WJ, NST, DB>(P, sm, bx, (int)by * BJ, bz, by == 0);
+}
+
+// "column passes": a workgroup owns a 256-column tile of A and a row slab and walks ALL columns of B in
+// 256-wide passes with a 128-wide last pass when at most 128 columns remain - no half-empty 256 x 256
+// tile (NJ = 368 -> 256 + 128, NJ = 624 -> 256 + 256 + 128), equal work per workgroup.  A's slab is
+// re-read by every pass (L2 / MALL).
+__global__ __launch_bounds__(512, 2) void gemm_tn3_passes_kernel(const G3TnArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    unsigned bx = blockIdx.x, by = 0, bz = blockIdx.z;
+    if (P.gx > 0) xcd_tile(P.gx, 1, P.gz, bx, by, bz);
+    for (int j0 = 0; j0 < P.nj; j0 += 256) {
+        if (j0 > 0) __syncthreads();  // the epilogue panels of the previous pass live in the ring
+        if (P.nj - j0 > 128)
+            gemm_tn3_body<256, 256, 4, 2, 3, false>(P, sm, bx, j0, bz, j0 == 0);
+        else
+            gemm_tn3_body<256, 128, 4, 2, 3, false>(P, sm, bx, j0, bz, j0 == 0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -834,10 +856,15 @@ static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
 G3TnPlan g3_tn_plan(int ni, int nj, int64_t rows) {
     G3TnPlan p;
     p.variant = tune_get("g3_tn_variant", 0);
-    // 256 x 256 tiles when both sides fill them (measured: wins from 32768 rows on with <= 2 column tiles)
-    if (!p.variant) p.variant = (ni >= 256 && nj >= 192 && nj <= 512 && rows >= 32768) ? 3 : 2;
+    // 256-column tiles of A when both sides fill them (measured: wins from 32768 rows on): whole 256 x 256
+    // tiles when B's width is (nearly) a multiple of 256, else column passes with a 128-wide last pass
+    // (NJ = 368: 373 vs 386 us; NJ = 624: 604 vs 907 us, fp32-operand kernel 660)
+    if (!p.variant) {
+        const int rem = nj % 256;
+        p.variant = !(ni >= 256 && nj >= 192 && rows >= 32768) ? 2 : (rem > 0 && rem <= 128 && nj > 256) ? 4 : 3;
+    }
     const int bi = p.variant == 2 ? 128 : 256, bj = p.variant == 3 ? 256 : 128;
-    const int64_t tiles = cdiv(ni, bi) * cdiv(nj, bj);
+    const int64_t tiles = p.variant == 4 ? cdiv(ni, 256) : cdiv(ni, bi) * cdiv(nj, bj);
     int64_t s = cdiv(tune_get("g3_tn_wgs", p.variant == 2 ? 512 : 256), tiles);
     const int64_t max_s = cdiv(rows, 256);  // at least 16 stages per split
     if (s > max_s) s = max_s;
@@ -868,7 +895,7 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     a.rows_per_split = plan.rows_per_split;
     a.safe = tune_get("g3_safe", 0) != 0;
     const int bi = plan.variant == 2 ? 128 : 256, bj = plan.variant == 3 ? 256 : 128;
-    dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)cdiv(a.nj, bj), (unsigned)plan.splits);
+    dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)(plan.variant == 4 ? 1 : cdiv(a.nj, bj)), (unsigned)plan.splits);
     a.gx = a.gy = a.gz = 0;
     if (tune_get("tn_xcd", 1)) {
         a.gx = (int)grid.x;
@@ -878,7 +905,17 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     }
     prof_before(2, st);
     int rc;
-    if (plan.variant == 1)
+    if (plan.variant == 4) {
+        constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;  // the 256 x 256 ring covers the 256 x 128 one
+        static bool raised = false;
+        if (!raised) {
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_passes_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = true;
+        }
+        hipLaunchKernelGGL(gemm_tn3_passes_kernel, grid, dim3(512), lds, st, a);
+        rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
+    } else if (plan.variant == 1)
         rc = launch_tn3_variant<256, 128, 4, 2, 4, true>(a, grid, st);
     else if (plan.variant == 3)
         rc = launch_tn3_variant<256, 256, 4, 2, 3, false>(a, grid, st);

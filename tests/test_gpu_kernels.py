@@ -307,8 +307,8 @@ def test_lstm_images(device, m, n, nin, variant):
 
 
 @pytest.mark.parametrize("rows,ni,nj", [(4096, 1024, 368), (2048, 96, 80), (4096, 45, 384), (65536, 384, 256),
-                                        (32, 7, 130)])
-@pytest.mark.parametrize("variant", [1, 2], ids=["256x128", "128x128"])
+                                        (32, 7, 130), (8192, 512, 624)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["256x128", "128x128", "256x256", "passes"])
 def test_gemm_tn_images(device, rows, ni, nj, variant):
     lib, check = _lib()
     g = th.Generator().manual_seed(rows + ni + nj)
@@ -316,10 +316,10 @@ def test_gemm_tn_images(device, rows, ni, nj, variant):
     a3 = _image(lib, check, device, _padded(a.to(device), _p4(ni)), ni)
     b3 = _image(lib, check, device, _padded(b.to(device), _p4(nj)), nj)
     ldc = _p4(nj) + 4
-    sb = lib.marl_gemm_tn_images_scratch(ni, nj, rows)
-    scratch = th.zeros(sb // 4 + 16, device=device)
 
     def run():
+        sb = lib.marl_gemm_tn_images_scratch(ni, nj, rows)  # (the split plan depends on the tile plan)
+        scratch = th.zeros(sb // 4 + 16, device=device)
         cd, cs = th.zeros(ni, ldc, device=device), th.zeros(ni, device=device)
         check(lib.marl_gemm_tn_images(a3.data_ptr(), b3.data_ptr(), cd.data_ptr(), ldc, ni, nj, rows, cs.data_ptr(),
                                       scratch.data_ptr(), sb, None))

@@ -21,7 +21,7 @@ for r, ni, nj in SHAPES:
     us0 = timeit(lambda: check(lib.marl_gemm_tn(ad.data_ptr(), ad.shape[1], bd.data_ptr(), bd.shape[1], cd.data_ptr(), cd.shape[1], ni, nj, r, scratch.data_ptr(), sb, None)))
     err0 = (cd[:, :nj].cpu().double() - ref).abs().max().item()
     a3, b3 = image(ad, ni), image(bd, nj)
-    for variant in (2, 1, 3):
+    for variant in (2, 3, 4):
         check(lib.marl_tune(b"g3_tn_variant", variant))
         c1 = th.full((ni, p4(nj)), 7.0, device=dev)
         cs = th.zeros(ni, device=dev)
