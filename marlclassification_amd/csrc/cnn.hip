@@ -1192,12 +1192,16 @@ __device__ __forceinline__ void fwd3_layer(const CnnFwdArgs& A, float* lds, int 
                     gs[0] = mean;
                     gs[1] = rstd;
                 }
+                float av[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float zv = acc0[r];
                     if (Ly.z) Ly.z[(orow * P + r) * (int64_t)cout + ch] = zv;
-                    A.u[orow * (int64_t)A.ldu + ch * P + r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                    av[r] = cnn_silu((zv - mean) * rstd * gm + bt);
+                    A.u[orow * (int64_t)A.ldu + ch * P + r] = av[r];
                 }
+                if (A.u3)  // (as in cnn_fwd2: four positions = four consecutive feature columns of U)
+                    img_store4(A.u3 + img_off(A.u3_row0 + orow, (ch * 4) >> 4, A.u3_steps), ch * 4, av[0], av[1], av[2], av[3]);
             }
         }
         MARL_F3_TS();
@@ -1422,8 +1426,10 @@ static size_t cnn_fwd_plan(CnnFwdArgs& a, int rb) {
 }
 
 int cnn_fwd_writes_image(const CnnFwdArgs& a) {
-    const int w = cnn_fwd2_which(a);  // Fwd2Resisc / Fwd2Mnist6: last layer = four positions per patch (mode 1)
-    return w == 1 || w == 2;
+    // Fwd2Resisc / Fwd2Mnist6 (mode-1 last layer) and the two AidCnn plans (packed last layer): the last
+    // layer has four positions per patch, a lane's four outputs are four consecutive columns of U
+    const int w = cnn_fwd2_which(a);
+    return w == 1 || w == 2 || w == 4 || w == 5;
 }
 
 int cnn_fwd_supported(const CnnFwdArgs& a0) {
