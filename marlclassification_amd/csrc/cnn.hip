@@ -140,7 +140,7 @@ void ts_report(const char* tag, long long* dev, int waves) {
 typedef float cf32x4 __attribute__((ext_vector_type(4)));
 
 // v_exp_f32 / v_rcp_f32 based (~1e-7 relative error, inside the 1e-5 parity budget)
-__device__ __forceinline__ float cnn_silu(float y) { return y * __frcp_rn(1.0f + __expf(-y)); }
+__device__ __forceinline__ float cnn_silu(float y) { return silu_fast(y); }
 
 __global__ __launch_bounds__(512) void cnn_fwd_kernel(const CnnFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1506,8 +1506,7 @@ constexpr int kDgradTiles = 4;  // row tiles per wave
 
 // v_exp_f32 / v_rcp_f32 based (~1e-7 relative error, inside the 1e-5 parity budget)
 __device__ __forceinline__ float cnn_silu_grad(float y) {
-    const float s = __frcp_rn(1.0f + __expf(-y));
-    return s * (1.0f + y * (1.0f - s));
+    return silu_grad_fast(y);
 }
 
 __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
@@ -1521,44 +1520,24 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int quad = lane >> 4, l16 = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * A.rb;
-    const int nrow = (int)(A.rows - row0 < A.rb ? A.rows - row0 : A.rb);
     const int cin = A.cin, cout = A.cout, hin = A.hin, hout = A.hout, P = A.P, Pin = A.Pin, G = A.G;
     const int zs = cout + 4, cs = cin + 4, cpg = (int)A.dcpg.d;
+    // PERSISTENT over chunks of rb patches (round 4): the row order of the tiles, the tap sets and the
+    // lane roles are the same for every full chunk - building them was a third of the kernel's VALU
+    // instructions when every chunk was its own workgroup - the next chunk is staged while this one is
+    // written out, and the affine partial sums of a workgroup stay in registers across its chunks
+    // (gridDim.x partial rows instead of one per chunk; the order of the sums is fixed by the grid).
+    const int nchunks = (int)((A.rows + A.rb - 1) / A.rb);
+    const int full_rows = A.rb;
 
 #ifdef MARL_KERNEL_TS
     MARL_TS_DECL(A.ts);
 #endif
     MARL_TS();
-    // ---- row order of the dA tiles: parity class major, then patch, then position
-    {
-        const int ne = (hin + 1) >> 1, no = hin >> 1;
-        int start = 0;
-        int cstart[5];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            cstart[c] = start;
-            start += nrow * ((c >> 1) ? no : ne) * ((c & 1) ? no : ne);
-        }
-        cstart[4] = start;
-        for (int m = tid; m < A.MT * 16; m += nthreads) {
-            int v = -1;
-            if (m < cstart[4]) {
-                int c = 0;
-                if (m >= cstart[1]) c = 1;
-                if (m >= cstart[2]) c = 2;
-                if (m >= cstart[3]) c = 3;
-                const int ny = (c >> 1) ? no : ne, nx = (c & 1) ? no : ne;
-                const int idx = m - cstart[c];
-                const int lr = idx / (ny * nx), q = idx - lr * ny * nx;
-                const int yi = q / nx, xi = q - yi * nx;
-                v = (lr << 16) | ((2 * yi + (c >> 1)) << 8) | (2 * xi + (c & 1));
-            }
-            perm[m] = v;
-        }
-    }
-    // ---- dZ_l, Z_{l-1} and the statistics of this chunk -> LDS
-    {
+    // ---- dZ_l, Z_{l-1} and the statistics of one chunk -> LDS
+    auto stage = [&](int chunk) {
+        const int64_t row0 = (int64_t)chunk * full_rows;
+        const int nrow = (int)(A.rows - row0 < full_rows ? A.rows - row0 : full_rows);
         const int M = nrow * P, c4 = cout >> 2;
         const float* src = A.dz + row0 * P * (int64_t)cout;
         for (int idx = tid; idx < M * c4; idx += nthreads) {
@@ -1572,197 +1551,242 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
             *reinterpret_cast<float4*>(Zin + m * cs + k) = *reinterpret_cast<const float4*>(zsrc + (int64_t)m * cin + k);
         }
         for (int idx = tid; idx < nrow * G * 2; idx += nthreads) gstat[idx] = A.gst[row0 * G * 2 + idx];
-    }
-    MARL_TS();
-    __syncthreads();
-    MARL_TS();
+    };
 
-    // ---- transposed convolution: wave w owns column tile nt = w % NT and a CONTIGUOUS range of
-    // row tiles (same parity class -> same taps, so one weight fragment feeds all of them);
-    // the accumulators stay in registers across the nine taps
-    {
-        const int NT = A.NT, wpn = nwaves / NT;
-        const int nt = wave % NT, wslot = wave / NT;
-        const bool wactive = wslot < wpn;  // nwaves need not be a multiple of NT
-        // row-tile range of this wave slot (equal-cost split made by the launcher)
-        const int tb = wactive ? A.tbeg[wslot] : 0, tpw = wactive ? A.tbeg[wslot + 1] - tb : 0;
-        cf32x4 acc[kDgradTiles];
-        // per row tile: this lane's row (patch base offset in Dz, input position) and the
-        // 9-bit set of taps that reach a valid output position; the wave-wide union of the
-        // sets is kept on the scalar unit so that skipped taps cost one scalar branch
-        int rbase[kDgradTiles], rpy[kDgradTiles], rpx[kDgradTiles], tmask[kDgradTiles];
-        unsigned wmask[kDgradTiles], wave_mask = 0;
+    // transposed convolution: wave w owns column tile nt = w % NT and a CONTIGUOUS range of row tiles
+    // (same parity class -> same taps, so one weight fragment feeds all of them)
+    const int NT = A.NT, wpn = nwaves / NT;
+    const int nt = wave % NT, wslot = wave / NT;
+    const bool wactive = wslot < wpn;  // nwaves need not be a multiple of NT
+    // row-tile range of this wave slot (equal-cost split made by the launcher)
+    const int tb = wactive ? A.tbeg[wslot] : 0, tpw = wactive ? A.tbeg[wslot + 1] - tb : 0;
+    // per row tile: this lane's row (patch base offset in Dz, input position) and the 9-bit set of
+    // taps that reach a valid output position; the wave-wide union of the sets is kept on the scalar
+    // unit so that skipped taps cost one scalar branch
+    int rbase[kDgradTiles], rpy[kDgradTiles], rpx[kDgradTiles], tmask[kDgradTiles];
+    unsigned wmask[kDgradTiles], wave_mask = 0;
+    int nrow_built = -1;  // the chunk height the tables were built for
+    int wr = nt * 16 + l16;
+    wr = wr < cin ? wr : cin - 1;
+    const int steps = (cout + 15) >> 4;
+    const float* wbase = A.wt + (int64_t)wr * A.ldwt + 4 * quad;
+    const int64_t tap_stride = (int64_t)cin * A.ldwt;
+
+    // GroupNorm + SiLU backward: wave w always works on group w % G (nwaves % G == 0), lane (cc, pslot)
+    // owns channel g * cpg + cc, so the affine partial sums have a single owner and a fixed order
+    const int g = wave % G, wpg = nwaves / G;
+    const int cc = lane % cpg, pslot = lane / cpg, pstep = 64 / cpg;
+    const int c = g * cpg + cc;
+    const float gm = A.gamma[c], bt = A.beta[c];
+    const float inv_cnt = 1.0f / (float)(Pin * cpg);
+    float pg = 0.f, pb = 0.f;
+
+    stage(blockIdx.x);
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t row0 = (int64_t)chunk * full_rows;
+        const int nrow = (int)(A.rows - row0 < full_rows ? A.rows - row0 : full_rows);
+        const bool rebuild = nrow != nrow_built;
+        // ---- row order of the dA tiles: parity class major, then patch, then position
+        if (rebuild) {
+            const int ne = (hin + 1) >> 1, no = hin >> 1;
+            int start = 0;
+            int cstart[5];
 #pragma unroll
-        for (int i = 0; i < kDgradTiles; ++i) {
-            acc[i] = cf32x4{0.f, 0.f, 0.f, 0.f};
-            const int mt = tb + i;
-            const int pk = (wactive && i < tpw && mt < A.MT) ? perm[mt * 16 + l16] : -1;
-            const int py = (pk >> 8) & 255, px = pk & 255;
-            rbase[i] = (pk >> 16) * P * zs + 4 * quad;
-            rpy[i] = py;
-            rpx[i] = px;
-            int my = 0, mx = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int ty = py + 1 - k, tx = px + 1 - k;
-                if (ty >= 0 && !(ty & 1) && (ty >> 1) < hout) my |= 1 << k;
-                if (tx >= 0 && !(tx & 1) && (tx >> 1) < hout) mx |= 1 << k;
+            for (int q = 0; q < 4; ++q) {
+                cstart[q] = start;
+                start += nrow * ((q >> 1) ? no : ne) * ((q & 1) ? no : ne);
             }
-            int tm = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (my & (1 << k)) tm |= mx << (3 * k);
-            tmask[i] = pk < 0 ? 0 : tm;
-            unsigned wm_ = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                if (__ballot((tmask[i] >> t) & 1) != 0ull) wm_ |= 1u << t;
-            wmask[i] = wm_;
-            wave_mask |= wm_;
-        }
-        int wr = nt * 16 + l16;
-        wr = wr < cin ? wr : cin - 1;
-        const int steps = (cout + 15) >> 4;
-        const float* wbase = A.wt + (int64_t)wr * A.ldwt + 4 * quad;
-        const int64_t tap_stride = (int64_t)cin * A.ldwt;
-        for (int tap = 0; tap < 9; ++tap) {
-            if (!((wave_mask >> tap) & 1u)) continue;  // none of this wave's rows sees this tap
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            for (int st0 = 0; st0 < steps; st0 += 4) {
-                float4 bq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kk = (st0 + j) * 16;
-                    const bool ok = st0 + j < steps && kk + 4 * quad < cout;
-                    const float4 v = *reinterpret_cast<const float4*>(wbase + tap * tap_stride + (ok ? kk : -4 * quad));
-                    bq[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            cstart[4] = start;
+            for (int m = tid; m < A.MT * 16; m += nthreads) {
+                int v = -1;
+                if (m < cstart[4]) {
+                    int q = 0;
+                    if (m >= cstart[1]) q = 1;
+                    if (m >= cstart[2]) q = 2;
+                    if (m >= cstart[3]) q = 3;
+                    const int ny = (q >> 1) ? no : ne, nx = (q & 1) ? no : ne;
+                    const int idx = m - cstart[q];
+                    const int lr = idx / (ny * nx), r = idx - lr * ny * nx;
+                    const int yi = r / nx, xi = r - yi * nx;
+                    v = (lr << 16) | ((2 * yi + (q >> 1)) << 8) | (2 * xi + (q & 1));
                 }
+                perm[m] = v;
+            }
+            nrow_built = nrow;
+        }
+        MARL_TS();
+        __syncthreads();
+        MARL_TS();
+        if (rebuild) {
+            wave_mask = 0;
 #pragma unroll
-                for (int i = 0; i < kDgradTiles; ++i) {
-                    if (!((wmask[i] >> tap) & 1u)) continue;
-                    const bool valid = (tmask[i] >> tap) & 1;
-                    const int off = rbase[i] + (((rpy[i] + 1 - kh) >> 1) * hout + ((rpx[i] + 1 - kw) >> 1)) * zs;
+            for (int i = 0; i < kDgradTiles; ++i) {
+                const int mt = tb + i;
+                const int pk = (wactive && i < tpw && mt < A.MT) ? perm[mt * 16 + l16] : -1;
+                const int py = (pk >> 8) & 255, px = pk & 255;
+                rbase[i] = (pk >> 16) * P * zs + 4 * quad;
+                rpy[i] = py;
+                rpx[i] = px;
+                int my = 0, mx = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int ty = py + 1 - k, tx = px + 1 - k;
+                    if (ty >= 0 && !(ty & 1) && (ty >> 1) < hout) my |= 1 << k;
+                    if (tx >= 0 && !(tx & 1) && (tx >> 1) < hout) mx |= 1 << k;
+                }
+                int tm = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (my & (1 << k)) tm |= mx << (3 * k);
+                tmask[i] = pk < 0 ? 0 : tm;
+                unsigned wm_ = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if (__ballot((tmask[i] >> t) & 1) != 0ull) wm_ |= 1u << t;
+                wmask[i] = wm_;
+                wave_mask |= wm_;
+            }
+        }
+        // ---- the accumulators stay in registers across the nine taps
+        {
+            cf32x4 acc[kDgradTiles];
+#pragma unroll
+            for (int i = 0; i < kDgradTiles; ++i) acc[i] = cf32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tap = 0; tap < 9; ++tap) {
+                if (!((wave_mask >> tap) & 1u)) continue;  // none of this wave's rows sees this tap
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                for (int st0 = 0; st0 < steps; st0 += 4) {
+                    float4 bq[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (st0 + j < steps) {
-                            float4 a = *reinterpret_cast<const float4*>(Dz + (valid ? off + (st0 + j) * 16 : 4 * quad));
-                            if (!valid || (st0 + j) * 16 + 4 * quad >= cout) a = make_float4(0.f, 0.f, 0.f, 0.f);
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[j].x, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[j].y, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[j].z, acc[i], 0, 0, 0);
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[j].w, acc[i], 0, 0, 0);
+                        const int kk = (st0 + j) * 16;
+                        const bool ok = st0 + j < steps && kk + 4 * quad < cout;
+                        const float4 v = *reinterpret_cast<const float4*>(wbase + tap * tap_stride + (ok ? kk : -4 * quad));
+                        bq[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kDgradTiles; ++i) {
+                        if (!((wmask[i] >> tap) & 1u)) continue;
+                        const bool valid = (tmask[i] >> tap) & 1;
+                        const int off = rbase[i] + (((rpy[i] + 1 - kh) >> 1) * hout + ((rpx[i] + 1 - kw) >> 1)) * zs;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (st0 + j < steps) {
+                                float4 a = *reinterpret_cast<const float4*>(Dz + (valid ? off + (st0 + j) * 16 : 4 * quad));
+                                if (!valid || (st0 + j) * 16 + 4 * quad >= cout) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[j].x, acc[i], 0, 0, 0);
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[j].y, acc[i], 0, 0, 0);
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[j].z, acc[i], 0, 0, 0);
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[j].w, acc[i], 0, 0, 0);
+                            }
                         }
+                    }
+                }
+            }
+            MARL_TS();
+            const int n = nt * 16 + l16;
+#pragma unroll
+            for (int i = 0; i < kDgradTiles; ++i) {
+                const int mt = tb + i;
+                if (wactive && i < tpw && mt < A.MT && n < cin) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pk = perm[mt * 16 + 4 * quad + r];
+                        if (pk >= 0)
+                            Da[((pk >> 16) * Pin + ((pk >> 8) & 255) * hin + (pk & 255)) * cs + n] = acc[i][r];
                     }
                 }
             }
         }
         MARL_TS();
-        const int n = nt * 16 + l16;
-#pragma unroll
-        for (int i = 0; i < kDgradTiles; ++i) {
-            const int mt = tb + i;
-            if (wactive && i < tpw && mt < A.MT && n < cin) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pk = perm[mt * 16 + 4 * quad + r];
-                    if (pk >= 0)
-                        Da[((pk >> 16) * Pin + ((pk >> 8) & 255) * hin + (pk & 255)) * cs + n] = acc[i][r];
-                }
-            }
-        }
-    }
-    MARL_TS();
-    __syncthreads();
-    MARL_TS();
+        __syncthreads();
+        MARL_TS();
 
-    // ---- GroupNorm + SiLU backward of layer l-1 on the LDS panels.  Wave w always works on
-    // group w % G (nwaves % G == 0), lane (cc, pslot) owns channel g * cpg + cc, so the affine
-    // partial sums have a single owner and a fixed order.
-    {
-        const int g = wave % G, wpg = nwaves / G;
-        const int cc = lane % cpg, pslot = lane / cpg, pstep = 64 / cpg;
-        const int c = g * cpg + cc;
-        const float gm = A.gamma[c], bt = A.beta[c];
-        const float inv_cnt = 1.0f / (float)(Pin * cpg);
-        float pg = 0.f, pb = 0.f;
-        constexpr int kKeep = 8;  // positions per lane kept in registers between the two passes
-        const bool keep = Pin <= kKeep * pstep;
-        for (int lr = wave / G; lr < nrow; lr += wpg) {
-            const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
-            const float* zr = Zin + lr * Pin * cs + c;
-            float* dr = Da + lr * Pin * cs + c;
-            float s1 = 0.f, s2 = 0.f;
-            if (keep) {
-                float xk[kKeep], dk[kKeep];
+        // ---- GroupNorm + SiLU backward of layer l-1 on the LDS panels
+        {
+            constexpr int kKeep = 8;  // positions per lane kept in registers between the two passes
+            const bool keep = Pin <= kKeep * pstep;
+            for (int lr = wave / G; lr < nrow; lr += wpg) {
+                const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+                const float* zr = Zin + lr * Pin * cs + c;
+                float* dr = Da + lr * Pin * cs + c;
+                float s1 = 0.f, s2 = 0.f;
+                if (keep) {
+                    float xk[kKeep], dk[kKeep];
 #pragma unroll
-                for (int u = 0; u < kKeep; ++u) {
-                    const int pos = pslot + u * pstep;
-                    xk[u] = dk[u] = 0.f;
-                    if (pos < Pin) {
-                        const float xh = (zr[pos * cs] - mean) * rstd;
-                        const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
-                        const float dxh = dy * gm;
-                        xk[u] = xh;
-                        dk[u] = dxh;
-                        s1 += dxh;
-                        s2 += dxh * xh;
-                        pg += dy * xh;
-                        pb += dy;
+                    for (int u = 0; u < kKeep; ++u) {
+                        const int pos = pslot + u * pstep;
+                        xk[u] = dk[u] = 0.f;
+                        if (pos < Pin) {
+                            const float xh = (zr[pos * cs] - mean) * rstd;
+                            const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
+                            const float dxh = dy * gm;
+                            xk[u] = xh;
+                            dk[u] = dxh;
+                            s1 += dxh;
+                            s2 += dxh * xh;
+                            pg += dy * xh;
+                            pb += dy;
+                        }
                     }
+                    const float m1 = wave_sum(s1) * inv_cnt, m2 = wave_sum(s2) * inv_cnt;
+#pragma unroll
+                    for (int u = 0; u < kKeep; ++u) {
+                        const int pos = pslot + u * pstep;
+                        if (pos < Pin) dr[pos * cs] = rstd * (dk[u] - m1 - xk[u] * m2);
+                    }
+                    continue;
+                }
+                for (int pos = pslot; pos < Pin; pos += pstep) {
+                    const float xh = (zr[pos * cs] - mean) * rstd;
+                    const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
+                    const float dxh = dy * gm;
+                    s1 += dxh;
+                    s2 += dxh * xh;
+                    pg += dy * xh;
+                    pb += dy;
                 }
                 const float m1 = wave_sum(s1) * inv_cnt, m2 = wave_sum(s2) * inv_cnt;
-#pragma unroll
-                for (int u = 0; u < kKeep; ++u) {
-                    const int pos = pslot + u * pstep;
-                    if (pos < Pin) dr[pos * cs] = rstd * (dk[u] - m1 - xk[u] * m2);
+                for (int pos = pslot; pos < Pin; pos += pstep) {
+                    const float xh = (zr[pos * cs] - mean) * rstd;
+                    const float dxh = dr[pos * cs] * cnn_silu_grad(gm * xh + bt) * gm;
+                    dr[pos * cs] = rstd * (dxh - m1 - xh * m2);
                 }
-                continue;
-            }
-            for (int pos = pslot; pos < Pin; pos += pstep) {
-                const float xh = (zr[pos * cs] - mean) * rstd;
-                const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
-                const float dxh = dy * gm;
-                s1 += dxh;
-                s2 += dxh * xh;
-                pg += dy * xh;
-                pb += dy;
-            }
-            const float m1 = wave_sum(s1) * inv_cnt, m2 = wave_sum(s2) * inv_cnt;
-            for (int pos = pslot; pos < Pin; pos += pstep) {
-                const float xh = (zr[pos * cs] - mean) * rstd;
-                const float dxh = dr[pos * cs] * cnn_silu_grad(gm * xh + bt) * gm;
-                dr[pos * cs] = rstd * (dxh - m1 - xh * m2);
             }
         }
-        for (int o = cpg; o < 64; o <<= 1) {
-            pg += __shfl_xor(pg, o);
-            pb += __shfl_xor(pb, o);
+        MARL_TS();
+        __syncthreads();
+        MARL_TS();
+        // ---- the next chunk's loads go out first (Dz, Zin and the statistics are free from here on),
+        // then dZ_{l-1} of this chunk -> global (coalesced)
+        if (chunk + (int)gridDim.x < nchunks) stage(chunk + (int)gridDim.x);
+        {
+            const int Mi = nrow * Pin, i4 = cin >> 2;
+            float* dst = A.dzin + row0 * Pin * (int64_t)cin;
+            for (int idx = tid; idx < Mi * i4; idx += nthreads) {
+                const int m = fdiv(idx, A.dc4i), k = (idx - m * i4) * 4;
+                *reinterpret_cast<float4*>(dst + (int64_t)m * cin + k) = *reinterpret_cast<const float4*>(Da + m * cs + k);
+            }
         }
-        if (pslot == 0) {
-            gsum[(wave * 2) * cpg + cc] = pg;
-            gsum[(wave * 2 + 1) * cpg + cc] = pb;
-        }
+        MARL_TS();
     }
-    MARL_TS();
+    // ---- affine partials of this workgroup
+    for (int o = cpg; o < 64; o <<= 1) {
+        pg += __shfl_xor(pg, o);
+        pb += __shfl_xor(pb, o);
+    }
+    if (pslot == 0) {
+        gsum[(wave * 2) * cpg + cc] = pg;
+        gsum[(wave * 2 + 1) * cpg + cc] = pb;
+    }
     __syncthreads();
-    MARL_TS();
-    // ---- dZ_{l-1} -> global (coalesced), affine partials of this workgroup
-    {
-        const int Mi = nrow * Pin, i4 = cin >> 2;
-        float* dst = A.dzin + row0 * Pin * (int64_t)cin;
-        for (int idx = tid; idx < Mi * i4; idx += nthreads) {
-            const int m = fdiv(idx, A.dc4i), k = (idx - m * i4) * 4;
-            *reinterpret_cast<float4*>(dst + (int64_t)m * cin + k) = *reinterpret_cast<const float4*>(Da + m * cs + k);
-        }
-        for (int e = tid; e < 2 * cin; e += nthreads) {
-            const int which = e >= cin, ch = e - which * cin;
-            const int g = fdiv(ch, A.dcpg), cc = ch - g * cpg;
-            float t = 0.f;
-            for (int w = g; w < nwaves; w += G) t += gsum[(w * 2 + which) * cpg + cc];
-            A.part[(size_t)blockIdx.x * 2 * cin + e] = t;
-        }
+    for (int e = tid; e < 2 * cin; e += nthreads) {
+        const int which = e >= cin, ch = e - which * cin;
+        const int gg = fdiv(ch, A.dcpg), c2 = ch - gg * cpg;
+        float t = 0.f;
+        for (int w = gg; w < nwaves; w += G) t += gsum[(w * 2 + which) * cpg + c2];
+        A.part[(size_t)blockIdx.x * 2 * cin + e] = t;
     }
-    MARL_TS();
 }
 
 static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
@@ -1853,10 +1877,57 @@ int cnn_dgrad_supported(const CnnDgradArgs& a0) {
     return cnn_dgrad_rb(a) > 0;
 }
 
-int cnn_dgrad_blocks(const CnnDgradArgs& a0) {
+// Persistent grid: as many workgroups as are resident at once (occupancy x CUs), never more than
+// there are chunks.  This is also the number of affine partial rows the kernel writes.
+static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
+    static int num_cu = 0;
+    static size_t occ_lds[8];
+    static int occ_val[8], occ_n = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        num_cu = prop.multiProcessorCount;
+    }
+    int occ = 0;
+    for (int i = 0; i < occ_n; ++i)
+        if (occ_lds[i] == lds) occ = occ_val[i];
+    if (!occ) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(cnn_dgrad_kernel), 512, lds) !=
+                hipSuccess || occ < 1)
+            occ = 1;
+        if (occ_n < 8) {
+            occ_lds[occ_n] = lds;
+            occ_val[occ_n++] = occ;
+        }
+    }
+    const int64_t cap = (int64_t)tune_get("dgrad_wgs", occ * num_cu);
+    const int64_t chunks = cdiv(a.rows, rb);
+    return (int)(chunks < cap ? chunks : (cap < 1 ? 1 : cap));
+}
+
+static void cnn_dgrad_raise_lds() {
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        raised = true;
+    }
+}
+
+// device-independent upper bound of cnn_dgrad_blocks (the workspace layout is computed without a GPU)
+int cnn_dgrad_blocks_max(const CnnDgradArgs& a0) {
     CnnDgradArgs a = a0;
     const int rb = cnn_dgrad_rb(a);
     return rb > 0 ? (int)cdiv(a.rows, rb) : 0;
+}
+
+int cnn_dgrad_blocks(const CnnDgradArgs& a0) {
+    CnnDgradArgs a = a0;
+    const int rb = cnn_dgrad_rb(a);
+    if (rb <= 0) return 0;
+    cnn_dgrad_raise_lds();
+    return cnn_dgrad_grid(a, rb, cnn_dgrad_plan(a, rb) * sizeof(float));
 }
 
 int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
@@ -1866,12 +1937,8 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
         return MARL_ELIMIT;
     }
     const size_t lds = cnn_dgrad_plan(a, rb) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        raised = true;
-    }
+    cnn_dgrad_raise_lds();
+    const int grid = cnn_dgrad_grid(a, rb, lds);
 #ifdef MARL_KERNEL_TS
     static long long* d_ts = nullptr;
     static int calls = 0;
@@ -1880,12 +1947,12 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
     a.ts = rec ? d_ts : nullptr;
 #endif
     prof_before(5, st);
-    hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)cdiv(a.rows, rb)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)grid), dim3(512), lds, st, a);
     prof_after(5, st);
     MARL_LAUNCH_CHECK();
 #ifdef MARL_KERNEL_TS
     if (rec) {
-        fprintf(stderr, "[ts] dgrad rb %d lds %zu cin %d cout %d blocks %d\n", rb, lds, a.cin, a.cout, (int)cdiv(a.rows, rb));
+        fprintf(stderr, "[ts] dgrad rb %d lds %zu cin %d cout %d blocks %d\n", rb, lds, a.cin, a.cout, grid);
         ts_report("cnn_dgrad", d_ts, 8);
     }
 #endif

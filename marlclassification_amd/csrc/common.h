@@ -25,6 +25,22 @@ int tune_set(const char* key, int value);
 // Sum over the 64 lanes of a wave on the VALU (DPP row shifts + row broadcasts, then a
 // readlane of lane 63): no LDS-pipe ds_bpermute round trips, result is wave-uniform.
 // Call with all 64 lanes active.
+// Activations on the transcendental unit: one v_exp_f32 and one v_rcp_f32 (each ~1 ulp; ~1e-7 absolute
+// error on a sigmoid, inside the 1e-5 parity budget and checked by the golden-vector tests).  libm's
+// expf is ~12 VALU instructions and an IEEE division 11 (so is __frcp_rn: it compiles to the full
+// v_div_scale / v_div_fmas / v_div_fixup sequence, not to v_rcp_f32); on kernels whose row passes are
+// VALU-issue-bound (cnn_dgrad, panel_*, ln_silu_*, sample) that was a third of their instructions.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_acc(float x) { return rcp_fast(1.0f + __expf(-x)); }
+// 1 - 2 / (1 + e^{2x}); e^{2x} -> inf gives 1, -> 0 gives -1
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * rcp_fast(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float silu_fast(float y) { return y * sigmoid_acc(y); }
+// d silu(y) / dy
+__device__ __forceinline__ float silu_grad_fast(float y) {
+    const float s = sigmoid_acc(y);
+    return s * (1.0f + y * (1.0f - s));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     int x = __float_as_int(v);
 #define MARL_DPP_ADD(ctrl, rmask)                         \
@@ -577,7 +593,7 @@ __device__ __forceinline__ void lstm_cell_bwd_at(const LstmBwdArgs& A, int64_t r
     const int n = A.n;
     float* g = A.gates + r * A.ldg + u;
     const float gi = g[0], gf = g[n], gg = g[2 * n], go = g[3 * n];
-    const float tc = tanhf(A.c_new[r * A.ldc + u]);
+    const float tc = tanh_fast(A.c_new[r * A.ldc + u]);
     const float dcv = dhv * go * (1.0f - tc * tc) + A.dc[r * A.lddc + u];
     g[0] = dcv * gg * gi * (1.0f - gi);
     g[n] = dcv * A.c_prev[r * A.ldc + u] * gf * (1.0f - gf);
@@ -602,7 +618,7 @@ __device__ __forceinline__ void lstm_cell_bwd_at4(const LstmBwdArgs& A, int64_t 
     float o[5][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float tc = tanhf(cn[q]);
+        const float tc = tanh_fast(cn[q]);
         const float dcv = dhv[q] * go[q] * (1.0f - tc * tc) + dcin[q];
         o[0][q] = dcv * gg[q] * gi[q] * (1.0f - gi[q]);
         o[1][q] = dcv * cp[q] * gf[q] * (1.0f - gf[q]);
@@ -777,7 +793,8 @@ struct CnnDgradArgs {
 #endif
 };
 int cnn_dgrad_supported(const CnnDgradArgs& a);
-int cnn_dgrad_blocks(const CnnDgradArgs& a);
+int cnn_dgrad_blocks(const CnnDgradArgs& a);      // partial rows the launch writes (persistent grid)
+int cnn_dgrad_blocks_max(const CnnDgradArgs& a);  // its device-independent upper bound
 int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------

@@ -472,7 +472,7 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
         upd_part(ln_bwd_blocks(r, d.n_m), d.n_m);
         for (int l = 0; l < d.L; ++l) upd_part(gn_bwd_blocks(nr, d.ch[l + 1]), d.ch[l + 1]);
         for (int l = 1; l < d.L; ++l)  // fused layer backward: one partial row per workgroup
-            if (e.dgrad_ok[l]) upd_part(cnn_dgrad_blocks(cnn_dgrad_shape(d, l)), d.ch[l]);
+            if (e.dgrad_ok[l]) upd_part(cnn_dgrad_blocks_max(cnn_dgrad_shape(d, l)), d.ch[l]);
         upd_tn(d.nC, d.nlb, nr);
         upd_tn(d.nlb, d.n_b, nr);
         upd_tn(1, d.nla, nr);

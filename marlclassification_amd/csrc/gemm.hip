@@ -20,16 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;          // row depth of one staged tile of the TN kernel
 
 
-// Gate non-linearities of the fused LSTM epilogue: v_exp_f32 / v_rcp_f32 based (~1e-7
-// absolute error, well inside the 1e-5 parity budget; checked by the golden-vector tests).
-// The accurate libm forms cost ~10 us per launch in the epilogue of a 120 us kernel.
-__device__ __forceinline__ float sigmoid_acc(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
-}
-__device__ __forceinline__ float tanh_fast(float x) {
-    // 1 - 2 / (1 + e^{2x}); e^{2x} -> inf gives 1, -> 0 gives -1
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
-}
+// (gate non-linearities of the fused LSTM epilogue: sigmoid_acc / tanh_fast of common.h; the accurate
+// libm forms cost ~10 us per launch in the epilogue of a 120 us kernel)
 
 // LDS-only workgroup barrier: the prefetch loads of the next K tile stay in flight across it
 // (a plain __syncthreads() also drains vmcnt).

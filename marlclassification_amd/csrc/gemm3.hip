@@ -31,10 +31,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 namespace {
 
-__device__ __forceinline__ float sigmoid_acc(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) {
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
-}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -36,10 +36,6 @@ namespace {
 constexpr int SK = 32;     // K depth of a staged tile (two 16-deep MFMA steps)
 constexpr int SROW = 80;   // LDS bytes per tile row: 32 bf16 + 16 B pad
 
-__device__ __forceinline__ float sigmoid_acc(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) {
-    return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
-}
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

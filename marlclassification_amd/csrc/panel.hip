@@ -26,11 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-__device__ __forceinline__ float silu_p(float y) { return y / (1.0f + expf(-y)); }
-__device__ __forceinline__ float silu_grad_p(float y) {
-    const float s = 1.0f / (1.0f + expf(-y));
-    return s * (1.0f + y * (1.0f - s));
-}
+__device__ __forceinline__ float silu_p(float y) { return silu_fast(y); }
+__device__ __forceinline__ float silu_grad_p(float y) { return silu_grad_fast(y); }
 
 // 16-row panels: R = Na*Nb = 4096 rows give 256 workgroups (one per CU); the f32 matrix-core
 // time of the widest layer (256 -> 384) is ~5 us per panel, half of what a 32-row panel on
@@ -887,7 +884,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                         float o0[4], o1[4], o2[4], o3[4], o4[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float tc = tanhf(cn_[q]);
+                            const float tc = tanh_fast(cn_[q]);
                             const float d = tot[q] * go_[q] * (1.0f - tc * tc) + dc_[q];
                             o0[q] = d * gg_[q] * gi_[q] * (1.0f - gi_[q]);
                             o1[q] = d * cp_[q] * gf_[q] * (1.0f - gf_[q]);

@@ -78,12 +78,8 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
-// d silu(y) / dy
-__device__ __forceinline__ float silu_grad(float y) {
-    const float s = 1.0f / (1.0f + expf(-y));
-    return s * (1.0f + y * (1.0f - s));
-}
+__device__ __forceinline__ float silu_f(float y) { return silu_fast(y); }
+__device__ __forceinline__ float silu_grad(float y) { return silu_grad_fast(y); }
 
 // ---------------------------------------------------------------------------
 // LayerNorm (eps 1e-5, biased variance, affine) + SiLU     (Linear-LN-SiLU blocks of

@@ -9,7 +9,7 @@
 
 namespace marl {
 
-__device__ __forceinline__ float sample_silu(float y) { return y / (1.0f + expf(-y)); }
+__device__ __forceinline__ float sample_silu(float y) { return silu_fast(y); }
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): a
 // counter-based generator - four 32-bit words per (key, counter), no state to carry between
