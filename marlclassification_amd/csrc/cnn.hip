@@ -1861,7 +1861,7 @@ static int cnn_dgrad_rb(CnnDgradArgs& a) {
     for (int rb = rb_max < 8 ? (rb_max < 1 ? 1 : rb_max) : 8; rb >= 1; --rb) {
         if (cnn_dgrad_plan(a, rb) * sizeof(float) > lds_cap) continue;
         if (a.MT > kDgradTiles * wpn || a.MT > 64) continue;
-        if (rb > 1 && cdiv(a.rows, rb) < 512) continue;
+        if (rb > 1 && cdiv(a.rows, rb) < tune_get("dgrad_min_chunks", 512)) continue;
         return rb;
     }
     return 0;
@@ -1901,7 +1901,8 @@ static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
             occ_val[occ_n++] = occ;
         }
     }
-    const int64_t cap = (int64_t)tune_get("dgrad_wgs", occ * num_cu);
+    int64_t cap = (int64_t)tune_get("dgrad_wgs", 0);  // <= 0: every workgroup resident at once
+    if (cap <= 0) cap = (int64_t)occ * num_cu;
     const int64_t chunks = cdiv(a.rows, rb);
     return (int)(chunks < cap ? chunks : (cap < 1 ? 1 : cap));
 }

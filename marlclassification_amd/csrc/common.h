@@ -695,6 +695,9 @@ struct PanelBwdProb {
     int cell_vec4;  // (filled by the launcher) the riding-along cell runs four units per thread
     // reported by the launcher: the gate-gradient images asked for (cellb.g3 / cell.g3) are written
     int cellb_img_done, cell_img_done;
+#ifdef MARL_KERNEL_TS
+    long long* ts;  // phase timestamps of one workgroup (debug builds only)
+#endif
 };
 int panel_bwd_blocks(int m);
 int panel_chain_blocks(int na, int nb);  // workgroups of a by_batch launch

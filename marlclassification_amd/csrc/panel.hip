@@ -573,6 +573,10 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
         rowmap[tid] = r;
     }
     lds_barrier();
+#ifdef MARL_KERNEL_TS
+    MARL_TS_DECL(P.ts);
+#endif
+    MARL_TS();
 
     // The saved pre-LayerNorm rows (and statistics) of a layer are requested one layer ahead: the
     // two rows of this wave for layer l + 1 fly while layer l's dX product runs.  Unconditional
@@ -660,7 +664,9 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
             *reinterpret_cast<float4*>(D + lr * ds + k) = v;
         }
     }
+    MARL_TS();
     lds_barrier();
+    MARL_TS();
 
     int prm_off = 0;
     for (int l = 0; l < P.nlayers; ++l) {
@@ -776,13 +782,16 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                 }
             }
         }
+        MARL_TS();
         lds_barrier();
+        MARL_TS();
         for (int c = tid; c < 2 * n; c += blockDim.x) {
             float t = 0.f;
             for (int w = 0; w < nwaves; ++w) t += colp[(size_t)w * 2 * n + c];
             Lr.part[(size_t)blockIdx.x * 2 * n + c] = t;
         }
         if (l + 1 < P.nlayers) zfetch(P.layer[l + 1]);
+        MARL_TS();
         // ---- dX = dz * W: out tiles over k_in columns, contraction over n
         const int nout = Lr.k_in, nt = (nout + 31) >> 5;
         const int ks = panel_ksplit(n, nt, nwaves);
@@ -829,6 +838,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
             }
             lds_barrier();
         }
+        MARL_TS();
         if (last && P.tail_lds) {
             // Final dX (+ the belief cell's elementwise backward) ROW-wise from the LDS panel: four
             // consecutive columns per thread, 16-byte loads of everything two items need before
@@ -913,6 +923,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                 }
             }
         }
+        MARL_TS();
         float* tmp = D;
         D = E;
         E = tmp;
@@ -987,6 +998,12 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     p.cell_img_done = p.has_cell && p.cell.g3 && p.cell_vec4;
     if (!p.cellb_img_done) p.cellb.skip_f32 = 0;  // (the fallback builds the image from the fp32 gradients)
     if (!p.cell_img_done) p.cell.skip_f32 = 0;
+#ifdef MARL_KERNEL_TS
+    static long long* d_ts = nullptr;
+    static int calls = 0;
+    const int rec = ts_begin(&d_ts, calls++);
+    p.ts = rec ? d_ts : nullptr;
+#endif
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
         const unsigned cblocks = (unsigned)cdiv(p.cell_rows * (p.cell_vec4 ? p.cell.n / 4 : p.cell.n), 64 * waves);
@@ -996,6 +1013,13 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     }
     prof_after(4, st);
     MARL_LAUNCH_CHECK();
+#ifdef MARL_KERNEL_TS
+    if (rec) {
+        fprintf(stderr, "[ts] panel_bwd layers %d waves %d lds %zu cell %d cellb %d tail_lds %d\n", p.nlayers, waves, lds,
+                p.has_cell, p.has_cellb, p.tail_lds);
+        ts_report("panel_bwd", d_ts, waves);
+    }
+#endif
     return MARL_OK;
 }
 

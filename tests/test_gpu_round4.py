@@ -170,3 +170,40 @@ def test_image_gemm_path_equals_the_fp32_operand_path(device, tag):
         a, b = res[0][1][k].double(), res[1][1][k].double()
         worst = max(worst, (a - b).abs().max().item() / max(1e-30, a.abs().max().item()))
     assert worst <= 2e-5, worst
+
+
+def test_persistent_cnn_backward_is_grid_independent(device):
+    """cnn_dgrad_kernel walks the chunks of 8 patches with a resident grid: the same gradients whether one
+    workgroup walks 17 chunks, a grid of its own size walks one each, or every patch is its own chunk - with
+    a ragged last chunk (665 rows = 83 * 8 + 1) that rebuilds the tile tables.  dZ is the same arithmetic in
+    every case; the affine partial sums are added in a grid-dependent (fixed per grid) order."""
+    from marlclassification_amd import engine as E
+
+    g = Golden("g1_conftest")
+    res = {}
+    try:
+        for name, knobs in (("rb1", {}), ("grid5", {"dgrad_min_chunks": 1, "dgrad_wgs": 5}),
+                            ("grid84", {"dgrad_min_chunks": 1, "dgrad_wgs": 100000})):
+            E.tune("dgrad_min_chunks", knobs.get("dgrad_min_chunks", 512))
+            E.tune("dgrad_wgs", knobs.get("dgrad_wgs", 0))
+            eng = _engine(g, device)
+            out = _forward(eng, g, device)
+            gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+            grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+            E.check(eng.lib.marl_profile_begin(5, 64))  # class 5: the fused layer-backward launches
+            eng.episode_backward(gp, gl, gv, grads)
+            ms, n = C.c_double(0), C.c_int(0)
+            E.check(eng.lib.marl_profile_end(C.byref(ms), C.byref(n)))
+            assert n.value >= 1, "cnn_dgrad_kernel did not run on this shape"
+            res[name] = {k: v.cpu().double() for k, v in grads.items()}
+    finally:
+        E.tune("dgrad_min_chunks", 512)
+        E.tune("dgrad_wgs", 0)
+    cnn = [k for k in res["rb1"] if "cnn" in k.lower() or "seq_conv" in k.lower()]
+    assert cnn, list(res["rb1"])[:8]
+    for other in ("grid5", "grid84"):
+        worst = 0.0
+        for k in res["rb1"]:
+            a, b = res["rb1"][k], res[other][k]
+            worst = max(worst, (a - b).abs().max().item() / max(1e-30, a.abs().max().item()))
+        assert worst <= 2e-6, (other, worst)
