@@ -207,3 +207,71 @@ def test_persistent_cnn_backward_is_grid_independent(device):
             a, b = res["rb1"][k], res[other][k]
             worst = max(worst, (a - b).abs().max().item() / max(1e-30, a.abs().max().item()))
         assert worst <= 2e-6, (other, worst)
+
+
+@pytest.mark.parametrize("tag,rep", [("c4_aid", 16), ("c5_synth", 32)])
+def test_full_size_c4_c5_replicas_match_the_oracle(device, tag, rep):
+    """C4 / C5 had numeric oracle checks at B = 2 / 1 only.  The oracle's small case tiled
+    along the batch to BASELINE.json's 32 images per GPU (C5: R = 2048 rows, 64 agents - the two-launch panel
+    path, the column-pass row contractions and the split-K slab counts of the benched size): every replica
+    reproduces the oracle's positions bit for bit (teacher-forced to its actions) and its logits / log-probs /
+    values within 1e-5; with the un-tiled batch's advantage statistics (phase 2 of marl_a2c_loss_fwd_bwd) the
+    tiled batch's gradient is the small batch's: every gradient entry within 1e-4 of its tensor's scale."""
+    from marlclassification_amd.engine import HipEngine
+    from oracle import marl_oracle as mo
+    from tests.test_gpu_episode import ATOL, BIG_CASES, _maxerr
+    from tests.util import uniform_params
+
+    cfg, na, nb, ns, shape = BIG_CASES[tag]
+    params = uniform_params(cfg, 7)
+    img = th.rand(nb, *shape, generator=th.Generator().manual_seed(11))
+    y = th.randint(0, cfg.nb_class, (nb,), generator=th.Generator().manual_seed(12))
+    inp = mo.draw_episode_inputs(cfg, na, nb, ns, shape[1:], 13)
+    tr, lo, grads = mo.train_iteration(params, cfg, img, y, inp, ns, 0.99)
+
+    def engine(batch):
+        eng = HipEngine(model_spec(cfg), device)
+        eng.configure(na, batch, ns, shape)
+        eng.pack({k: v.to(device) for k, v in params.items()})
+        return eng
+
+    small = [t.to(device) for t in (inp.pos0, inp.h0, inp.c0, inp.hc0, inp.cc0, inp.q)]
+    eng1 = engine(nb)
+    out1 = eng1.episode_forward(img.to(device), *small, tr.step_actions.to(device), True)
+    stats = eng1.a2c_loss(out1, y.to(device), 0.99, phase=1)[4].clone()
+    del eng1, out1
+
+    def tile(t, dim):
+        return th.cat([t] * rep, dim=dim)
+
+    eng = engine(nb * rep)
+    big = [tile(inp.pos0, 1), tile(inp.h0, 1), tile(inp.c0, 1), tile(inp.hc0, 1), tile(inp.cc0, 1), tile(inp.q, 2)]
+    out = eng.episode_forward(tile(img, 0).to(device), *[t.to(device) for t in big],
+                              tile(tr.step_actions, 2).to(device), True)
+
+    def replicas(t, bdim):  # [.., nb * rep, ..] -> [rep, .., nb, ..]
+        s = list(t.shape)
+        s[bdim:bdim + 1] = [rep, nb]
+        return t.reshape(s).movedim(bdim, 0)
+
+    pos = replicas(out.step_pos.cpu(), 2)
+    assert th.equal(pos, tr.step_pos.expand_as(pos)), "positions of a replica differ"
+    for name, got, ref in (("preds", out.step_preds, tr.step_preds), ("logp", out.step_log_probas, tr.step_log_probas),
+                           ("values", out.step_values, tr.step_values)):
+        r = replicas(got.cpu(), 2)
+        assert (r.double() - ref.detach().double()).abs().max().item() <= ATOL, name
+        assert th.equal(r[0], r[rep - 1]), f"{name}: replicas are not bit-identical"
+    yb = tile(y, 0).to(device)
+    bufs = eng.a2c_loss(out, yb, 0.99, phase=1)
+    assert th.allclose(bufs[4], stats * rep, rtol=1e-9), (bufs[4], stats * rep)
+    bufs[4].copy_(stats)  # standardize with the small batch's own n / sum / sum of squares
+    gp, gl, gv, sc, _ = eng.a2c_loss(out, yb, 0.99, phase=2, bufs=bufs)
+    assert abs(sc[0].item() - lo.loss.item()) <= 5e-5 * max(1.0, abs(lo.loss.item()))
+    g_out = {k: th.zeros_like(v, device=device) for k, v in params.items()}
+    eng.episode_backward(gp, gl, gv, g_out)
+    bad = {}
+    for k, ref in grads.items():
+        err = _maxerr(g_out[k], ref)
+        if not err <= 1e-4 * ref.abs().max().item() + 1e-7:
+            bad[k.replace("_ModelsWrapper__", "")] = "%.2e/%.2e" % (err, ref.abs().max().item())
+    assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
