@@ -275,3 +275,22 @@ def test_full_size_c4_c5_replicas_match_the_oracle(device, tag, rep):
         if not err <= 1e-4 * ref.abs().max().item() + 1e-7:
             bad[k.replace("_ModelsWrapper__", "")] = "%.2e/%.2e" % (err, ref.abs().max().item())
     assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
+
+
+@pytest.mark.parametrize("na,nb,ns,shape", [
+    (2, 1, 1, (3, 28, 28)),     # one image, one step: no recurrence, no reverse loop
+    (3, 1, 4, (3, 28, 28)),     # a single image: R = 3 rows, every kernel one ragged tile
+    (5, 7, 1, (3, 28, 28)),     # one step, R = 35
+    (16, 3, 2, (3, 40, 36)),    # 16 agents: the chained panels (all agents of an image per workgroup), ragged
+    (17, 2, 2, (3, 40, 36)),    # one agent more than a 16-row panel holds: the unchained panel path
+])
+def test_edge_sizes_match_the_oracle(device, na, nb, ns, shape):
+    """Smallest / ragged episode shapes (empty-ish and ragged inputs): teacher-forced rollout,
+    loss and EVERY gradient against the oracle, then the free-running trajectory."""
+    from oracle import marl_oracle as mo
+    from tests.test_gpu_round2 import _check_against_oracle, _engine as engine2, _oracle_case
+
+    cfg = mo.OracleConfig("mnist", 6, 32, 32, 8, 12, 8, 10, 48, 48)
+    params, img, y, inp = _oracle_case(cfg, na, nb, ns, shape)
+    eng = engine2(cfg, device, na, nb, ns, shape, params)
+    _check_against_oracle(eng, cfg, device, params, img, y, inp, ns)
