@@ -1164,18 +1164,22 @@ int launch_lstm_cell_bwd2(const float* dh0, int lddh0, float* dc0, int lddc0, fl
 // Policy output layer + softmax + multinomial (argmax p/q) + log-prob + bounded move
 // (networks/policy.py:15-16, core/agent.py:53-61, core/environment.py:56-66,128-150)
 // ---------------------------------------------------------------------------
+template <int MAXA>
 __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.R) return;
-    float p[MARL_MAX_ACTIONS];
-    sample_row_logits(A, r, p, lane);
-    sample_finish(A, r, p, lane);
+    float p[MAXA];
+    sample_row_logits<MAXA>(A, r, p, lane);
+    sample_finish<MAXA>(A, r, p, lane);
 }
 
 int launch_sample(const SampleArgs& a, hipStream_t st) {
     if (a.nA > MARL_MAX_ACTIONS) return MARL_ELIMIT;
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);
+    if (a.nA <= 4 && tune_get("sample_maxa4", 1))
+        hipLaunchKernelGGL(sample_kernel<4>, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(sample_kernel<MARL_MAX_ACTIONS>, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }

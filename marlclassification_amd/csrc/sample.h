@@ -35,10 +35,14 @@ __device__ __forceinline__ float philox_u01(uint32_t v) { return ((float)(v >> 8
 
 // p[j] += sum over this lane's columns base + lane + 64u of a[u] * w1[j][col]; the output
 // layer's rows are read four actions at a time so that all loads of a group are in flight
+// (MAXA: compile-time bound of the action loops - 4 for the usual four moves, MARL_MAX_ACTIONS otherwise.
+// The loops are fully unrolled; at 16 the kernel was 24 KB of code of which a four-action model executes a
+// quarter, branching over the rest line by line)
+template <int MAXA>
 __device__ __forceinline__ void sample_logits_chunk(const SampleArgs& A, const float (&a)[8], int base,
-                                                    float (&p)[MARL_MAX_ACTIONS], int lane) {
+                                                    float (&p)[MAXA], int lane) {
 #pragma unroll
-    for (int j0 = 0; j0 < MARL_MAX_ACTIONS; j0 += 4) {
+    for (int j0 = 0; j0 < MAXA; j0 += 4) {
         if (j0 < A.nA) {
             float wv[4][8];
 #pragma unroll
@@ -63,11 +67,11 @@ __device__ __forceinline__ void sample_logits_chunk(const SampleArgs& A, const f
 }
 
 // One wave = one row r: the activation row is read into registers 512 columns at a time
-__device__ __forceinline__ void sample_row_logits(const SampleArgs& A, int r, float (&p)[MARL_MAX_ACTIONS],
-                                                  int lane) {
+template <int MAXA>
+__device__ __forceinline__ void sample_row_logits(const SampleArgs& A, int r, float (&p)[MAXA], int lane) {
     const float* ar = A.a_pol + (size_t)r * A.ld_a;
 #pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) p[j] = 0.f;
+    for (int j = 0; j < MAXA; ++j) p[j] = 0.f;
     for (int base = 0; base < A.nla; base += 512) {
         float a[8];
 #pragma unroll
@@ -75,16 +79,16 @@ __device__ __forceinline__ void sample_row_logits(const SampleArgs& A, int r, fl
             const int k = base + lane + 64 * u;
             a[u] = k < A.nla ? ar[k] : 0.f;
         }
-        sample_logits_chunk(A, a, base, p, lane);
+        sample_logits_chunk<MAXA>(A, a, base, p, lane);
     }
 }
 
 // p[] holds this lane's partial logits of row r; every lane of the wave must call this
-__device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float (&p)[MARL_MAX_ACTIONS],
-                                              int lane) {
+template <int MAXA>
+__device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float (&p)[MAXA], int lane) {
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j) {
+    for (int j = 0; j < MAXA; ++j) {
         if (j < A.nA) {
             p[j] = wave_sum(p[j]) + A.b1[j];
             mx = fmaxf(mx, p[j]);
@@ -94,7 +98,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
     }
     float den = 0.f;
 #pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+    for (int j = 0; j < MAXA; ++j)
         if (j < A.nA) {
             p[j] = expf(p[j] - mx);
             den += p[j];
@@ -102,7 +106,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
     int act = 0;
     float best = -INFINITY, pa = 0.f;
 #pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+    for (int j = 0; j < MAXA; ++j)
         if (j < A.nA) {
             p[j] = p[j] / den;
             if (A.noise) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
         // th.multinomial(p, 1) == argmax_j p_j / q_j with q ~ Exp(1) (core/agent.py:53-55); here
         // q_j = -log(u_j) from this row's own Philox stream (wave-uniform, every lane agrees)
 #pragma unroll
-        for (int j0 = 0; j0 < MARL_MAX_ACTIONS; j0 += 4) {
+        for (int j0 = 0; j0 < MAXA; j0 += 4) {
             if (j0 < A.nA) {
                 const uint64_t ctr = A.rng_ctr + (A.rng_off_dev ? (*A.rng_off_dev << 16) : 0ull);
                 const Philox4 u = philox4x32_10(A.rng_seed, ctr, (uint32_t)r, (uint32_t)(j0 >> 2));
@@ -138,7 +142,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
     if (!A.step_logp) {  // standalone step API: probabilities only
         if (lane == 0)
 #pragma unroll
-            for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+            for (int j = 0; j < MAXA; ++j)
                 if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
         return;
     }
@@ -147,7 +151,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
         act = fa < 0 ? 0 : (fa >= A.nA ? A.nA - 1 : fa);
     }
 #pragma unroll
-    for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+    for (int j = 0; j < MAXA; ++j)
         if (j == act) pa = p[j];
     // every lane computes the move (wave-uniform), lane 0 stores it
     const int pi0 = A.pos_in[r * 2], pi1 = A.pos_in[r * 2 + 1];
@@ -156,7 +160,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
     const int n0 = ok ? q0 : pi0, n1 = ok ? q1 : pi1;
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < MARL_MAX_ACTIONS; ++j)
+        for (int j = 0; j < MAXA; ++j)
             if (j < A.nA) A.probs[(size_t)r * A.nA + j] = p[j];
         A.actions_i32[r] = act;
         A.step_logp[r] = logf(pa);
