@@ -130,8 +130,10 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         const int r = ((int)blockIdx.x - B.panel_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
         if (r >= B.sample.R) return;
         float p[MARL_MAX_ACTIONS];
+        SamplePre<MARL_MAX_ACTIONS> S;
+        sample_prefetch<MARL_MAX_ACTIONS>(B.sample, r, threadIdx.x & 63, S);
         sample_row_logits<MARL_MAX_ACTIONS>(B.sample, r, p, threadIdx.x & 63);
-        sample_finish<MARL_MAX_ACTIONS>(B.sample, r, p, threadIdx.x & 63);
+        sample_finish<MARL_MAX_ACTIONS>(B.sample, r, p, threadIdx.x & 63, S);
         return;
     }
     const PanelFwdProb& P = B.p[blockIdx.y];

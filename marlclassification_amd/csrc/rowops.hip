@@ -1170,8 +1170,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.R) return;
     float p[MAXA];
+    SamplePre<MAXA> S;
+    sample_prefetch<MAXA>(A, r, lane, S);
     sample_row_logits<MAXA>(A, r, p, lane);
-    sample_finish<MAXA>(A, r, p, lane);
+    sample_finish<MAXA>(A, r, p, lane, S);
 }
 
 int launch_sample(const SampleArgs& a, hipStream_t st) {

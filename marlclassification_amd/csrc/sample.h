@@ -50,9 +50,10 @@ __device__ __forceinline__ void sample_logits_chunk(const SampleArgs& A, const f
                 const int j = j0 + jj < A.nA ? j0 + jj : A.nA - 1;
                 const float* wj = A.w1 + (size_t)j * A.ldw;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 8; ++u) {  // (clamped address, no branch between two loads)
                     const int k = base + lane + 64 * u;
-                    wv[jj][u] = k < A.nla ? wj[k] : 0.f;
+                    const float v = wj[k < A.nla ? k : 0];
+                    wv[jj][u] = k < A.nla ? v : 0.f;
                 }
             }
 #pragma unroll
@@ -77,20 +78,71 @@ __device__ __forceinline__ void sample_row_logits(const SampleArgs& A, int r, fl
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = base + lane + 64 * u;
-            a[u] = k < A.nla ? ar[k] : 0.f;
+            const float v = ar[k < A.nla ? k : 0];
+            a[u] = k < A.nla ? v : 0.f;
         }
         sample_logits_chunk<MAXA>(A, a, base, p, lane);
     }
 }
 
+// Everything of a row whose address does not depend on the draw, requested BEFORE the logits are waited
+// for: the kernel is one dependent chain per row (loads -> logits -> draw -> move -> embedding) and every
+// load left inside the chain costs it a round trip (the ISA of the round-3 form had ~35 dependent waits).
+template <int MAXA>
+struct SamplePre {
+    float b1[MAXA];
+    float nz[MAXA];
+    uint64_t ctr;
+    int pi0, pi1, forced;
+    // position embedding: this lane's four consecutive columns 4 * lane .. + 3 (pe_nd <= 256, aligned)
+    bool pe_fast;
+    float4 qb, qw[4], qg, qbt;
+};
+__device__ __forceinline__ bool sample_pe_fast(const SampleArgs& A) {
+    const uintptr_t al = (uintptr_t)A.pe_W | (uintptr_t)A.pe_b | (uintptr_t)A.pe_gamma | (uintptr_t)A.pe_beta |
+                         (uintptr_t)A.pe_z | (uintptr_t)A.pe_out;
+    return A.pe_W && A.step_logp && (al & 15) == 0 && A.pe_nd <= 256 && ((A.pe_nd | A.pe_ldz | A.pe_ldo) & 3) == 0 &&
+           (A.pe_col0 & 3) == 0;
+}
+template <int MAXA>
+__device__ __forceinline__ void sample_prefetch(const SampleArgs& A, int r, int lane, SamplePre<MAXA>& S) {
+#pragma unroll
+    for (int j = 0; j < MAXA; ++j) S.b1[j] = A.b1[j < A.nA ? j : A.nA - 1];
+    if (A.noise) {
+        const float* nr = A.noise + (size_t)r * A.nA;
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) S.nz[j] = nr[j < A.nA ? j : A.nA - 1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAXA; ++j) S.nz[j] = 1.0f;
+    }
+    S.ctr = A.rng_ctr + (A.rng_off_dev ? (*A.rng_off_dev << 16) : 0ull);
+    S.pi0 = S.pi1 = S.forced = 0;
+    if (A.step_logp) {
+        S.pi0 = A.pos_in[r * 2];
+        S.pi1 = A.pos_in[r * 2 + 1];
+        if (A.forced) S.forced = (int)A.forced[r];
+    }
+    S.pe_fast = sample_pe_fast(A);
+    if (S.pe_fast) {
+        const int j4 = 4 * lane < A.pe_nd ? 4 * lane : 0;
+        S.qb = *reinterpret_cast<const float4*>(A.pe_b + j4);
+        S.qg = *reinterpret_cast<const float4*>(A.pe_gamma + j4);
+        S.qbt = *reinterpret_cast<const float4*>(A.pe_beta + j4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S.qw[q] = *reinterpret_cast<const float4*>(A.pe_W + 4 * (j4 + q));
+    }
+}
+
 // p[] holds this lane's partial logits of row r; every lane of the wave must call this
 template <int MAXA>
-__device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float (&p)[MAXA], int lane) {
+__device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float (&p)[MAXA], int lane,
+                                              const SamplePre<MAXA>& S) {
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) {
         if (j < A.nA) {
-            p[j] = wave_sum(p[j]) + A.b1[j];
+            p[j] = wave_sum(p[j]) + S.b1[j];
             mx = fmaxf(mx, p[j]);
         } else {
             p[j] = 0.f;
@@ -110,7 +162,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
         if (j < A.nA) {
             p[j] = p[j] / den;
             if (A.noise) {
-                const float sc = p[j] / A.noise[(size_t)r * A.nA + j];
+                const float sc = p[j] / S.nz[j];
                 if (sc > best) {
                     best = sc;
                     act = j;
@@ -123,8 +175,7 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
 #pragma unroll
         for (int j0 = 0; j0 < MAXA; j0 += 4) {
             if (j0 < A.nA) {
-                const uint64_t ctr = A.rng_ctr + (A.rng_off_dev ? (*A.rng_off_dev << 16) : 0ull);
-                const Philox4 u = philox4x32_10(A.rng_seed, ctr, (uint32_t)r, (uint32_t)(j0 >> 2));
+                const Philox4 u = philox4x32_10(A.rng_seed, S.ctr, (uint32_t)r, (uint32_t)(j0 >> 2));
                 const uint32_t uv[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -147,15 +198,20 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
         return;
     }
     if (A.forced) {  // teacher forcing; out-of-range indices are clamped like transition_kernel does
-        const int fa = (int)A.forced[r];
+        const int fa = S.forced;
         act = fa < 0 ? 0 : (fa >= A.nA ? A.nA - 1 : fa);
     }
+    int mv0 = 0, mv1 = 0;  // (a select chain: the table sits in the kernel arguments)
 #pragma unroll
     for (int j = 0; j < MAXA; ++j)
-        if (j == act) pa = p[j];
+        if (j == act) {
+            pa = p[j];
+            mv0 = A.table[j][0];
+            mv1 = A.table[j][1];
+        }
     // every lane computes the move (wave-uniform), lane 0 stores it
-    const int pi0 = A.pos_in[r * 2], pi1 = A.pos_in[r * 2 + 1];
-    const int q0 = pi0 + A.table[act][0], q1 = pi1 + A.table[act][1];
+    const int pi0 = S.pi0, pi1 = S.pi1;
+    const int q0 = pi0 + mv0, q1 = pi1 + mv1;
     const bool ok = q0 >= 0 && q0 + A.f < A.H && q1 >= 0 && q1 + A.f < A.W;
     const int n0 = ok ? q0 : pi0, n1 = ok ? q1 : pi1;
     if (lane == 0) {
@@ -180,6 +236,42 @@ __device__ __forceinline__ void sample_finish(const SampleArgs& A, int r, float 
         if (lane == 0 && A.pe_npos) {
             A.pe_npos[(size_t)r * 4] = p0;
             A.pe_npos[(size_t)r * 4 + 1] = p1;
+        }
+        if (S.pe_fast) {
+            // four consecutive columns per lane, every parameter already in registers
+            const bool on = 4 * lane < nd;
+            const float b4[4] = {S.qb.x, S.qb.y, S.qb.z, S.qb.w}, g4[4] = {S.qg.x, S.qg.y, S.qg.z, S.qg.w};
+            const float t4[4] = {S.qbt.x, S.qbt.y, S.qbt.z, S.qbt.w};
+            float v[4], sm = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = on ? b4[q] + p0 * S.qw[q].x + p1 * S.qw[q].y : 0.f;
+                sm += v[q];
+            }
+            if (on) *reinterpret_cast<float4*>(A.pe_z + (size_t)r * A.pe_ldz + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+            const float mean = wave_sum(sm) / (float)nd;
+            float qq = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dd = on ? v[q] - mean : 0.f;
+                qq += dd * dd;
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)nd + 1e-5f);
+            if (lane == 0 && A.pe_stats) {
+                A.pe_stats[(size_t)r * 2] = mean;
+                A.pe_stats[(size_t)r * 2 + 1] = rstd;
+            }
+            if (on) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = sample_silu((v[q] - mean) * rstd * g4[q] + t4[q]);
+                *reinterpret_cast<float4*>(A.pe_out + (size_t)r * A.pe_ldo + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
+                if (A.pe_img) {  // the same values into the image of U[t+1]
+                    const int col = A.pe_col0 + 4 * lane;
+                    img_store4(A.pe_img + img_off((int64_t)A.pe_row0 + r, col >> 4, A.pe_steps), col, o[0], o[1], o[2], o[3]);
+                }
+            }
+            return;
         }
         float s = 0.f;
         for (int j = lane; j < nd; j += 64) {
