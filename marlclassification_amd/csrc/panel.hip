@@ -122,18 +122,21 @@ __host__ __device__ inline int panel_ksplit(int K, int nt, int nwaves) {
 // ===========================================================================
 // forward
 // ===========================================================================
-template <bool SAMPLE>
+// SAMPLE: 0 = panels only; 4 / MARL_MAX_ACTIONS = sampling workgroups ride along behind the panel ones, with
+// the action loops of sample.h bounded at that many actions
+template <int SAMPLE>
 __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (SAMPLE && (int)blockIdx.x >= B.panel_blocks) {
+    if (SAMPLE > 0 && (int)blockIdx.x >= B.panel_blocks) {
         // ride-along sampling workgroup: one wave per row of the policy activations
         const int r = ((int)blockIdx.x - B.panel_blocks) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
         if (r >= B.sample.R) return;
-        float p[MARL_MAX_ACTIONS];
-        SamplePre<MARL_MAX_ACTIONS> S;
-        sample_prefetch<MARL_MAX_ACTIONS>(B.sample, r, threadIdx.x & 63, S);
-        sample_row_logits<MARL_MAX_ACTIONS>(B.sample, r, p, threadIdx.x & 63);
-        sample_finish<MARL_MAX_ACTIONS>(B.sample, r, p, threadIdx.x & 63, S);
+        constexpr int MAXA = SAMPLE > 0 ? SAMPLE : 4;
+        float p[MAXA];
+        SamplePre<MAXA> S;
+        sample_prefetch<MAXA, false>(B.sample, r, threadIdx.x & 63, S);
+        sample_row_logits<MAXA>(B.sample, r, p, threadIdx.x & 63);
+        sample_finish<MAXA>(B.sample, r, p, threadIdx.x & 63, S);
         return;
     }
     const PanelFwdProb& P = B.p[blockIdx.y];
@@ -496,12 +499,11 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
     }
     static bool raised = false;
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fwd_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kPanelMaxLds));
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fwd_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kPanelMaxLds));
+        const void* kerns[3] = {reinterpret_cast<const void*>(panel_fwd_kernel<0>),
+                                reinterpret_cast<const void*>(panel_fwd_kernel<4>),
+                                reinterpret_cast<const void*>(panel_fwd_kernel<MARL_MAX_ACTIONS>)};
+        for (const void* kf : kerns)
+            MARL_HIP_CHECK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelMaxLds));
         raised = true;
     }
     unsigned pblocks = 0;
@@ -520,10 +522,13 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
     if (b.has_sample && b.count == 1) {
         b.panel_blocks = (int)pblocks;
         const unsigned sblocks = (unsigned)cdiv(b.sample.R, waves);
-        hipLaunchKernelGGL(panel_fwd_kernel<true>, dim3(pblocks + sblocks, 1), dim3(64 * waves), lds, st, b);
+        if (b.sample.nA <= 4)
+            hipLaunchKernelGGL(panel_fwd_kernel<4>, dim3(pblocks + sblocks, 1), dim3(64 * waves), lds, st, b);
+        else
+            hipLaunchKernelGGL(panel_fwd_kernel<MARL_MAX_ACTIONS>, dim3(pblocks + sblocks, 1), dim3(64 * waves), lds, st, b);
     } else {
         b.has_sample = 0;
-        hipLaunchKernelGGL(panel_fwd_kernel<false>, dim3(pblocks, (unsigned)b.count), dim3(64 * waves),
+        hipLaunchKernelGGL(panel_fwd_kernel<0>, dim3(pblocks, (unsigned)b.count), dim3(64 * waves),
                            lds, st, b);
     }
     prof_after(4, st);
@@ -543,7 +548,10 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
 // ===========================================================================
 constexpr int kBwdMaxCols = kPanelMaxCols;  // columns per lane in the row pass: widths up to 384
 
-template <bool CELL>
+// MAXC: LayerNorm columns per lane the row pass is unrolled for (widths up to 64 * MAXC).  The chained
+// encoder / decoder backward of the README dimensions has widths <= 128: two column slots instead of six
+// are a third of the row pass's instructions and 24 fewer registers.
+template <bool CELL, int MAXC>
 __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (CELL && (int)blockIdx.x >= P.panel_blocks) {
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
     // The saved pre-LayerNorm rows (and statistics) of a layer are requested one layer ahead: the
     // two rows of this wave for layer l + 1 fly while layer l's dX product runs.  Unconditional
     // loads (padding rows read row 0) so that no wait is widened by a branch.
-    float zpre[2][kBwdMaxCols], mpre[2], rpre[2];
+    float zpre[2][MAXC], mpre[2], rpre[2];
     auto zfetch = [&](const PanelBwdLayer& L) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
             mpre[i] = L.stats[rr * 2];
             rpre[i] = L.stats[rr * 2 + 1];
 #pragma unroll
-            for (int u = 0; u < kBwdMaxCols; ++u) {
+            for (int u = 0; u < MAXC; ++u) {
                 const int c = lane + 64 * u;
                 zpre[i][u] = c < L.n ? L.z[rr * L.ldz + c] : 0.f;
             }
@@ -721,9 +729,9 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
         // lives in registers between the statistics and the dz pass.
         {
             constexpr int RPW = 2;  // launcher guarantees >= 8 waves for the 16 rows
-            float pg[kBwdMaxCols], pb[kBwdMaxCols], g[kBwdMaxCols], bt[kBwdMaxCols];
+            float pg[MAXC], pb[MAXC], g[MAXC], bt[MAXC];
 #pragma unroll
-            for (int u = 0; u < kBwdMaxCols; ++u) {
+            for (int u = 0; u < MAXC; ++u) {
                 const int c = lane + 64 * u;
                 pg[u] = pb[u] = 0.f;
                 g[u] = c < n ? lgamma[c] : 0.f;
@@ -736,13 +744,13 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                 if (lr < kPanelRows) {  // wave-uniform
                     const int row = rowmap[lr];
                     const bool rv = row >= 0;
-                    float xh[kBwdMaxCols], dxh[kBwdMaxCols];
+                    float xh[MAXC], dxh[MAXC];
                     float s1 = 0.f, s2 = 0.f, rstd = 0.f;
                     if (rv) {
                         const float mean = mpre[i];
                         rstd = rpre[i];
 #pragma unroll
-                        for (int u = 0; u < kBwdMaxCols; ++u) {
+                        for (int u = 0; u < MAXC; ++u) {
                             const int c = lane + 64 * u;
                             xh[u] = dxh[u] = 0.f;
                             if (c < n) {
@@ -757,11 +765,11 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
                         }
                     } else {
 #pragma unroll
-                        for (int u = 0; u < kBwdMaxCols; ++u) xh[u] = dxh[u] = 0.f;
+                        for (int u = 0; u < MAXC; ++u) xh[u] = dxh[u] = 0.f;
                     }
                     const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
 #pragma unroll
-                    for (int u = 0; u < kBwdMaxCols; ++u) {
+                    for (int u = 0; u < MAXC; ++u) {
                         const int c = lane + 64 * u;
                         if (c < n16) {
                             float dzv = 0.f;
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(768, 4) void panel_bwd_kernel(const PanelBwdProb P)
             }
             float* cw = colp + (size_t)wave * 2 * n;
 #pragma unroll
-            for (int u = 0; u < kBwdMaxCols; ++u) {
+            for (int u = 0; u < MAXC; ++u) {
                 const int c = lane + 64 * u;
                 if (c < n) {
                     cw[c] = pg[u];
@@ -985,12 +993,12 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     }
     static bool raised = false;
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_bwd_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kPanelMaxLds));
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_bwd_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kPanelMaxLds));
+        const void* kerns[4] = {reinterpret_cast<const void*>(panel_bwd_kernel<false, 2>),
+                                reinterpret_cast<const void*>(panel_bwd_kernel<true, 2>),
+                                reinterpret_cast<const void*>(panel_bwd_kernel<false, kBwdMaxCols>),
+                                reinterpret_cast<const void*>(panel_bwd_kernel<true, kBwdMaxCols>)};
+        for (const void* kf : kerns)
+            MARL_HIP_CHECK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelMaxLds));
         raised = true;
     }
     const unsigned pblocks = p.by_batch > 0 ? (unsigned)cdiv(p.g_nb, p.by_batch) : (unsigned)cdiv(p.m, kPanelRows);
@@ -1006,12 +1014,18 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     const int rec = ts_begin(&d_ts, calls++);
     p.ts = rec ? d_ts : nullptr;
 #endif
+    const int maxc = nmax <= 128 && tune_get("panel_bwd_maxc", 1) ? 2 : kBwdMaxCols;
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
         const unsigned cblocks = (unsigned)cdiv(p.cell_rows * (p.cell_vec4 ? p.cell.n / 4 : p.cell.n), 64 * waves);
-        hipLaunchKernelGGL(panel_bwd_kernel<true>, dim3(pblocks + cblocks), dim3(64 * waves), lds, st, p);
+        if (maxc == 2)
+            hipLaunchKernelGGL((panel_bwd_kernel<true, 2>), dim3(pblocks + cblocks), dim3(64 * waves), lds, st, p);
+        else
+            hipLaunchKernelGGL((panel_bwd_kernel<true, kBwdMaxCols>), dim3(pblocks + cblocks), dim3(64 * waves), lds, st, p);
+    } else if (maxc == 2) {
+        hipLaunchKernelGGL((panel_bwd_kernel<false, 2>), dim3(pblocks), dim3(64 * waves), lds, st, p);
     } else {
-        hipLaunchKernelGGL(panel_bwd_kernel<false>, dim3(pblocks), dim3(64 * waves), lds, st, p);
+        hipLaunchKernelGGL((panel_bwd_kernel<false, kBwdMaxCols>), dim3(pblocks), dim3(64 * waves), lds, st, p);
     }
     prof_after(4, st);
     MARL_LAUNCH_CHECK();

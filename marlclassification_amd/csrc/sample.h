@@ -104,7 +104,8 @@ __device__ __forceinline__ bool sample_pe_fast(const SampleArgs& A) {
     return A.pe_W && A.step_logp && (al & 15) == 0 && A.pe_nd <= 256 && ((A.pe_nd | A.pe_ldz | A.pe_ldo) & 3) == 0 &&
            (A.pe_col0 & 3) == 0;
 }
-template <int MAXA>
+// (PE = false: without the embedding's parameters - for the ride-along form inside the 80-register panel kernel)
+template <int MAXA, bool PE = true>
 __device__ __forceinline__ void sample_prefetch(const SampleArgs& A, int r, int lane, SamplePre<MAXA>& S) {
 #pragma unroll
     for (int j = 0; j < MAXA; ++j) S.b1[j] = A.b1[j < A.nA ? j : A.nA - 1];
@@ -123,8 +124,8 @@ __device__ __forceinline__ void sample_prefetch(const SampleArgs& A, int r, int 
         S.pi1 = A.pos_in[r * 2 + 1];
         if (A.forced) S.forced = (int)A.forced[r];
     }
-    S.pe_fast = sample_pe_fast(A);
-    if (S.pe_fast) {
+    S.pe_fast = PE && sample_pe_fast(A);
+    if (PE && S.pe_fast) {
         const int j4 = 4 * lane < A.pe_nd ? 4 * lane : 0;
         S.qb = *reinterpret_cast<const float4*>(A.pe_b + j4);
         S.qg = *reinterpret_cast<const float4*>(A.pe_gamma + j4);
