@@ -119,6 +119,75 @@ __host__ __device__ inline int panel_ksplit(int K, int nt, int nwaves) {
     return ks < 1 ? 1 : ks;
 }
 
+// LayerNorm + SiLU row pass of the forward panel kernel: wave w owns rows w, w + nwaves, ...; a row lives
+// in registers (NC columns per lane: widths up to 64 * NC), two-pass statistics with VALU wave reductions,
+// result written over the LDS panel (next layer's input) and to global.  NC = 2 for the message chain's
+// widths (<= 128) is a third of the six-slot form's instructions.
+template <int NC>
+__device__ __forceinline__ void panel_ln_rows(const PanelLayer& Lr, float* outp, int ys, int n, const float* lgamma,
+                                              const float* lbeta, const int* rowmap, int wave, int nwaves, int lane)
+{
+    constexpr int RPW = 4;  // launcher guarantees >= 4 waves for the 16 rows
+    float g[NC], bt[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int c = lane + 64 * u;
+        g[u] = c < n ? lgamma[c] : 0.f;
+        bt[u] = c < n ? lbeta[c] : 0.f;
+    }
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int lr = wave + i * nwaves;
+        if (lr < kPanelRows) {  // wave-uniform
+            float* zr = outp + lr * ys;
+            const int row = rowmap[lr];
+            float v[NC];
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int c = lane + 64 * u;
+                v[u] = c < n ? zr[c] : 0.f;
+                sm += v[u];
+                if (Lr.z && row >= 0 && c < n) Lr.z[(size_t)row * Lr.ldz + c] = v[u];
+            }
+            const float mean = wave_sum(sm) * inv_n;
+            float q = 0.f;
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int c = lane + 64 * u;
+                const float d = c < n ? v[u] - mean : 0.f;
+                v[u] = d;
+                q += d * d;
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + 1e-5f);
+            float* arow = Lr.a + (size_t)(row < 0 ? 0 : row) * Lr.lda;
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int c = lane + 64 * u;
+                if (c < n) {
+                    const float av = silu_p(v[u] * rstd * g[u] + bt[u]);
+                    zr[c] = av;
+                    if (row >= 0) arow[c] = av;
+                }
+            }
+            if (Lr.stats && lane == 0 && row >= 0) {
+                Lr.stats[(size_t)row * 2] = mean;
+                Lr.stats[(size_t)row * 2 + 1] = rstd;
+            }
+            if (Lr.a3 && row >= 0) {
+                // the row's activations are in the LDS panel (written by this wave just above): four
+                // consecutive columns per lane -> 8-byte pieces of the three image planes
+                for (int c4 = 4 * lane; c4 < n; c4 += 256) {
+                    const float4 t = *reinterpret_cast<const float4*>(zr + c4);
+                    const int col = Lr.a3_col0 + c4;
+                    img_store4(Lr.a3 + img_off((int64_t)Lr.a3_row0 + row, col >> 4, Lr.a3_steps), col, t.x, t.y, t.z, t.w);
+                }
+            }
+        }
+    }
+}
+
 // ===========================================================================
 // forward
 // ===========================================================================
@@ -356,70 +425,11 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         MARL_TS();
         lds_barrier();
         MARL_TS();
-        // LayerNorm + SiLU: wave w owns rows w, w + nwaves, ...; a row lives in registers (<= 6
-        // columns per lane), two-pass statistics with VALU wave reductions, result written
-        // over the LDS panel (next layer's input) and to global.
-        {
-            constexpr int RPW = 4;  // launcher guarantees >= 4 waves for the 16 rows
-            float g[kPanelMaxCols], bt[kPanelMaxCols];
-#pragma unroll
-            for (int u = 0; u < kPanelMaxCols; ++u) {
-                const int c = lane + 64 * u;
-                g[u] = c < n ? lgamma[c] : 0.f;
-                bt[u] = c < n ? lbeta[c] : 0.f;
-            }
-            const float inv_n = 1.0f / (float)n;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int lr = wave + i * nwaves;
-                if (lr < kPanelRows) {  // wave-uniform
-                    float* zr = outp + lr * ys;
-                    const int row = rowmap[lr];
-                    float v[kPanelMaxCols];
-                    float sm = 0.f;
-#pragma unroll
-                    for (int u = 0; u < kPanelMaxCols; ++u) {
-                        const int c = lane + 64 * u;
-                        v[u] = c < n ? zr[c] : 0.f;
-                        sm += v[u];
-                        if (Lr.z && row >= 0 && c < n) Lr.z[(size_t)row * Lr.ldz + c] = v[u];
-                    }
-                    const float mean = wave_sum(sm) * inv_n;
-                    float q = 0.f;
-#pragma unroll
-                    for (int u = 0; u < kPanelMaxCols; ++u) {
-                        const int c = lane + 64 * u;
-                        const float d = c < n ? v[u] - mean : 0.f;
-                        v[u] = d;
-                        q += d * d;
-                    }
-                    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + 1e-5f);
-                    float* arow = Lr.a + (size_t)(row < 0 ? 0 : row) * Lr.lda;
-#pragma unroll
-                    for (int u = 0; u < kPanelMaxCols; ++u) {
-                        const int c = lane + 64 * u;
-                        if (c < n) {
-                            const float av = silu_p(v[u] * rstd * g[u] + bt[u]);
-                            zr[c] = av;
-                            if (row >= 0) arow[c] = av;
-                        }
-                    }
-                    if (Lr.stats && lane == 0 && row >= 0) {
-                        Lr.stats[(size_t)row * 2] = mean;
-                        Lr.stats[(size_t)row * 2 + 1] = rstd;
-                    }
-                    if (Lr.a3 && row >= 0) {
-                        // the row's activations are in the LDS panel (written by this wave just above): four
-                        // consecutive columns per lane -> 8-byte pieces of the three image planes
-                        for (int c4 = 4 * lane; c4 < n; c4 += 256) {
-                            const float4 t = *reinterpret_cast<const float4*>(zr + c4);
-                            const int col = Lr.a3_col0 + c4;
-                            img_store4(Lr.a3 + img_off((int64_t)Lr.a3_row0 + row, col >> 4, Lr.a3_steps), col, t.x, t.y, t.z, t.w);
-                        }
-                    }
-                }
-            }
-        }
+        // LayerNorm + SiLU row pass (panel_ln_rows above), unrolled for this layer's width
+        if (n <= 128)
+            panel_ln_rows<2>(Lr, outp, ys, n, lgamma, lbeta, rowmap, wave, nwaves, lane);
+        else
+            panel_ln_rows<kPanelMaxCols>(Lr, outp, ys, n, lgamma, lbeta, rowmap, wave, nwaves, lane);
         MARL_TS();
         lds_barrier();
         MARL_TS();
