@@ -544,6 +544,7 @@ struct PanelFwdBatch {
     // optional (count == 1): extra workgroups behind the panel ones run the sampling kernel's
     // rows (one wave per row) - an independent small kernel riding along in the same launch
     int has_sample, panel_blocks;
+    int ln_narrow_max;  // LayerNorm widths up to this use the two-column-slot row pass (launcher: 128, knob off: 0)
     SampleArgs sample;
 #ifdef MARL_KERNEL_TS
     long long* ts;  // phase timestamps of one workgroup (debug builds only)

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(768, 6) void panel_fwd_kernel(const PanelFwdBatch B
         lds_barrier();
         MARL_TS();
         // LayerNorm + SiLU row pass (panel_ln_rows above), unrolled for this layer's width
-        if (n <= 128)
+        if (n <= B.ln_narrow_max)
             panel_ln_rows<2>(Lr, outp, ys, n, lgamma, lbeta, rowmap, wave, nwaves, lane);
         else
             panel_ln_rows<kPanelMaxCols>(Lr, outp, ys, n, lgamma, lbeta, rowmap, wave, nwaves, lane);
@@ -516,6 +516,7 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
             MARL_HIP_CHECK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelMaxLds));
         raised = true;
     }
+    b.ln_narrow_max = tune_get("panel_ln_narrow", 1) ? 128 : 0;  // widths that take the two-slot row pass
     unsigned pblocks = 0;
     for (int i = 0; i < b.count; ++i) {
         const PanelFwdProb& p = b.p[i];

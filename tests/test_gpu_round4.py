@@ -294,3 +294,33 @@ def test_edge_sizes_match_the_oracle(device, na, nb, ns, shape):
     params, img, y, inp = _oracle_case(cfg, na, nb, ns, shape)
     eng = engine2(cfg, device, na, nb, ns, shape, params)
     _check_against_oracle(eng, cfg, device, params, img, y, inp, ns)
+
+
+@pytest.mark.parametrize("tag", ["g2_mnist_c1", "g4_resisc_b2"])
+def test_size_specialised_kernels_equal_the_general_ones(device, tag):
+    """sample_kernel<4> (action loops bounded at 4), the two-column-slot LayerNorm row passes of the panel
+    kernels (widths <= 128): the same arithmetic in the same order as the general instantiations - the rollout
+    and every gradient are BIT-identical with the knobs off."""
+    from marlclassification_amd import engine as E
+
+    g = Golden(tag)
+    res = {}
+    knobs = ("sample_maxa4", "panel_bwd_maxc", "panel_ln_narrow")
+    try:
+        for mode in (0, 1):
+            for k in knobs:
+                E.tune(k, mode)
+            eng = _engine(g, device)
+            out = _forward(eng, g, device)
+            gp, gl, gv, sc, st = eng.a2c_loss(out, g.y.to(device), g.gamma)
+            grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+            eng.episode_backward(gp, gl, gv, grads)
+            res[mode] = (out, {k: v.cpu() for k, v in grads.items()})
+    finally:
+        for k in knobs:
+            E.tune(k, 1)
+    a, b = res[0][0], res[1][0]
+    for name in ("step_pos", "step_actions", "step_preds", "step_log_probas", "step_values"):
+        assert th.equal(getattr(a, name), getattr(b, name)), name
+    for k in res[0][1]:
+        assert th.equal(res[0][1][k], res[1][1][k]), k
