@@ -592,8 +592,10 @@ static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void
     // launch: position embedding) also write its image when all of them are on the path and the column
     // ranges keep 8-byte image pieces whole; else (and for step 0, whose embedding comes from the
     // stand-alone kernel) one image pass over U[t] runs ahead of the LSTM launch
+    CnnFwdArgs probe = cnn_fwd_shape(c.d);  // (with the fragment-order weight copies the AidCnn kernels ask for)
+    for (int l = 0; l < c.d.L; ++l) probe.layer[l].wfrag = c.w.wf[4 * l] ? c.W + c.w.wf[4 * l] : nullptr;
     c.u3_by_producers = c.e.g3 && tune_get("g3_lstm", 1) != 0 && tune_get("g3_u3", 1) != 0 && c.e.fused_fwd &&
-                        cnn_fwd_writes_image(cnn_fwd_shape(c.d)) && use_panels(c.d) && !use_side_stream() &&
+                        cnn_fwd_writes_image(probe) && use_panels(c.d) && !use_side_stream() &&
                         ((c.d.nf | c.d.n_mo | c.d.n_d) & 3) == 0;
     return MARL_OK;
 }
