@@ -1706,6 +1706,45 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
         {
             constexpr int kKeep = 8;  // positions per lane kept in registers between the two passes
             const bool keep = Pin <= kKeep * pstep;
+            // Fewer patches in the chunk than waves per group (one-patch chunks of the wide first layers: half of
+            // the waves had no row): `share` waves split the positions of one (patch, group) and exchange their
+            // two statistics sums through LDS - every wave then has exactly one row, so the barriers stay uniform
+            const int share = (!keep && nrow < wpg && wpg % nrow == 0) ? wpg / nrow : 1;
+            if (share > 1) {
+                const int slot = wave / G, lr = slot / share, part = slot - lr * share;
+                const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
+                const float* zr = Zin + lr * Pin * cs + c;
+                float* dr = Da + lr * Pin * cs + c;
+                float s1 = 0.f, s2 = 0.f;
+                for (int pos = pslot + part * pstep; pos < Pin; pos += pstep * share) {
+                    const float xh = (zr[pos * cs] - mean) * rstd;
+                    const float dy = dr[pos * cs] * cnn_silu_grad(gm * xh + bt);
+                    const float dxh = dy * gm;
+                    s1 += dxh;
+                    s2 += dxh * xh;
+                    pg += dy * xh;
+                    pb += dy;
+                }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    gsum[wave * 2] = s1;
+                    gsum[wave * 2 + 1] = s2;
+                }
+                lds_barrier();
+                float t1 = 0.f, t2 = 0.f;
+                for (int q = 0; q < share; ++q) {  // fixed order: the same sums in every wave of the row
+                    const int w2 = g + G * (lr * share + q);
+                    t1 += gsum[w2 * 2];
+                    t2 += gsum[w2 * 2 + 1];
+                }
+                const float m1 = t1 * inv_cnt, m2 = t2 * inv_cnt;
+                for (int pos = pslot + part * pstep; pos < Pin; pos += pstep * share) {
+                    const float xh = (zr[pos * cs] - mean) * rstd;
+                    const float dxh = dr[pos * cs] * cnn_silu_grad(gm * xh + bt) * gm;
+                    dr[pos * cs] = rstd * (dxh - m1 - xh * m2);
+                }
+            } else {
             for (int lr = wave / G; lr < nrow; lr += wpg) {
                 const float mean = gstat[(lr * G + g) * 2], rstd = gstat[(lr * G + g) * 2 + 1];
                 const float* zr = Zin + lr * Pin * cs + c;
@@ -1752,6 +1791,7 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
                     const float dxh = dr[pos * cs] * cnn_silu_grad(gm * xh + bt) * gm;
                     dr[pos * cs] = rstd * (dxh - m1 - xh * m2);
                 }
+            }
             }
         }
         MARL_TS();
