@@ -2075,24 +2075,34 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
     const int Pin = A.hin * A.hin;
     // input items of this thread: patch-in-chunk, LDS float offset, global offset inside the
     // patch's source (image plane offset for the first layer, Z_{l-1} element otherwise)
-    int it_lr[PI], it_lo[PI], it_go[PI];
+    // (LEAN: the deep-prefetch first-layer form recomputes an item's indices where it needs them - three
+    // tables of 14 registers kept the kernel at 146 VGPRs = one workgroup per CU, and with one 16x16-output
+    // patch per chunk nothing then hides a chunk's two barriers and its staging)
+    constexpr bool LEAN = FIRST && PI > 4;
+    constexpr int NIT = LEAN ? 1 : PI;
+    int it_lr[NIT], it_lo[NIT], it_go[NIT];
     float4 gm4 = make_float4(0.f, 0.f, 0.f, 0.f), bt4 = gm4;
     int zi_g = 0;
-    if (FIRST) {
+    // (t: the thread index - an opaque per-call copy in the LEAN form, or hipcc hoists the chunk-invariant
+    // index math out of the chunk loop and the registers are back)
+    auto first_item = [&](int t, int i, int& lr_, int& lo_, int& go_) __attribute__((always_inline)) {
         const int ff = Pin, pe = cin * ff;
+        const int idx = t + i * 512;
+        lr_ = -1;
+        lo_ = go_ = 0;
+        if (idx < rb * pe) {
+            const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
+            const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
+            const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
+            lr_ = lr;
+            lo_ = lr * in_per + ((iy + 1) * hp + ix + 1) * cs + ci;
+            go_ = (ci * A.H + iy) * A.W + ix;
+        }
+    };
+    if constexpr (FIRST) {
+        if (!LEAN) {
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int idx = tid + i * 512;
-            it_lr[i] = -1;
-            it_lo[i] = it_go[i] = 0;
-            if (idx < rb * pe) {
-                const int lr = fdiv(idx, A.dpe), e = idx - lr * pe;
-                const int ci = fdiv(e, A.dff), e2 = e - ci * ff;
-                const int iy = fdiv(e2, A.df), ix = e2 - iy * A.hin;
-                it_lr[i] = lr;
-                it_lo[i] = lr * in_per + ((iy + 1) * hp + ix + 1) * cs + ci;
-                it_go[i] = (ci * A.H + iy) * A.W + ix;
-            }
+            for (int i = 0; i < NIT; ++i) first_item(tid, i, it_lr[i], it_lo[i], it_go[i]);
         }
     } else {
         const int c4i = cin >> 2;
@@ -2135,14 +2145,23 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
             pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) pd[i] = *reinterpret_cast<const float4*>(dsrc + (int64_t)m * cout);
         }
-        if (FIRST) {
+        if constexpr (FIRST) {
+            int tv = tid;
+            if (LEAN) asm volatile("" : "+v"(tv));
 #pragma unroll
             for (int i = 0; i < PI; ++i) {
                 pr[i] = 0.f;
-                if ((unsigned)it_lr[i] < (unsigned)nrow) {
-                    const int64_t r = row0 + it_lr[i];
+                int lr_, lo_, go_;
+                if (LEAN) {
+                    first_item(tv, i, lr_, lo_, go_);
+                } else {
+                    lr_ = it_lr[LEAN ? 0 : i];
+                    go_ = it_go[LEAN ? 0 : i];
+                }
+                if ((unsigned)lr_ < (unsigned)nrow) {
+                    const int64_t r = row0 + lr_;
                     const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
-                    const int64_t off = (r % A.nb) * plane + (int64_t)p0 * A.W + p1 + it_go[i];
+                    const int64_t off = (r % A.nb) * plane + (int64_t)p0 * A.W + p1 + go_;
                     pr[i] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
                 }
             }
@@ -2173,10 +2192,20 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
                 bsum.w += pd[i].w;
             }
         }
-        if (FIRST) {
+        if constexpr (FIRST) {
+            int tv = tid;
+            if (LEAN) asm volatile("" : "+v"(tv));
 #pragma unroll
-            for (int i = 0; i < PI; ++i)
-                if ((unsigned)it_lr[i] < (unsigned)nrow) In[it_lo[i]] = pr[i];
+            for (int i = 0; i < PI; ++i) {
+                int lr_, lo_, go_;
+                if (LEAN) {
+                    first_item(tv, i, lr_, lo_, go_);
+                } else {
+                    lr_ = it_lr[LEAN ? 0 : i];
+                    lo_ = it_lo[LEAN ? 0 : i];
+                }
+                if ((unsigned)lr_ < (unsigned)nrow) In[lo_] = pr[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < PI; ++i) {
