@@ -177,15 +177,30 @@ def cpu_baseline(budget_s: float = 25.0) -> dict:
     }
 
 
-def matrix_products_note(lib, rows: int) -> str:
-    """what the matrix kernels of THIS run do, read back from the library's knobs"""
+def matrix_products_note(lib, cfg) -> str:
+    """what the matrix kernels of THIS run do: the library's own decisions for this configuration
+    (marl_plan_query), not a re-derivation of them"""
     if lib.marl_tune_get(b"mfma_split", 1) == 0:
         return "exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, gemm.hip): knob mfma_split = 0"
+
+    def plan(key: bytes) -> bool:
+        v = C.c_int(0)
+        if lib.marl_plan_query(C.byref(cfg), 1, key, C.byref(v)) != 0:
+            raise SystemExit("marl_plan_query failed: " + lib.marl_last_error().decode())
+        return bool(v.value)
+
     note = ("fp32 results from three-term bf16 splits: six bf16 MFMA products per fp32 product, fp32 accumulate "
             "(gemm_split.hip: fp32 operands split while staged)")
-    if lib.marl_tune_get(b"g3", 1) != 0 and rows % 32 == 0 and min(C3["n_b"], C3["n_a"]) >= lib.marl_tune_get(b"g3_min_units", 128):
-        note += ("; LSTM cells, in-loop backward batch, batched heads, dU and the four large weight gradients on operand "
-                 "images pre-split by their producers and staged by LDS-DMA (gemm3.hip: knob g3 = 1)")
+    if plan(b"g3"):
+        on = ["in-loop backward batch, batched heads, dU"]
+        if plan(b"g3_lstm"):
+            on.insert(0, "LSTM cells")
+        if plan(b"g3_tn"):
+            on.append("the four large weight gradients")
+        note += ("; " + ", ".join(on) + " on operand images pre-split by their producers and staged by LDS-DMA "
+                 "(gemm3.hip; marl_plan_query)")
+        if plan(b"small_r"):
+            note += "; small-batch tile plans (tiles < 2 x CUs)"
     return note
 
 
@@ -386,16 +401,16 @@ def main() -> None:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
         # THIS round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if they cover it
         # (only if they were taken from THIS library: the file carries the sha256 of csrc/*.hip|*.h)
-        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_traffic.json")
         if nb == 256 and is_c3 and not args.rollout_only and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
                 tj = json.load(f)
             ent = tj.get(str(dom))
             if ent and tj.get("src_sha256") == csrc_sha256():
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r04_traffic.json, sources match)"
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r05_traffic.json, sources match)"
             elif ent:
-                roofline["traffic_unit"] = ("null: profiles/r04_traffic.json was measured on other kernel "
+                roofline["traffic_unit"] = ("null: profiles/r05_traffic.json was measured on other kernel "
                                             "sources (sha256 differs)")
     if distributed:
         dist.barrier()
@@ -420,7 +435,7 @@ def main() -> None:
                 "batch_per_gpu": nb, "global_batch": nb * world,
                 "parallelism": f"dp{world}",
                 "rng": "torch" if args.torch_rng else "library (Philox4x32-10)",
-                "matrix_products": matrix_products_note(lib, NA * nb),
+                "matrix_products": matrix_products_note(lib, eng.cfg),
                 "launch": "hipGraph replay" if args.graph else "eager",
             },
             "roofline": roofline, "cpu_baseline": cpu,

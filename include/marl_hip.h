@@ -320,6 +320,13 @@ int marl_profile_end(double* total_ms, int* launches);
 int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t,
                       int64_t* offset_floats, int* ld);
 
+/* Which kernel family the library picks for `cfg` under the current knobs (bench.py's `matrix_products`
+ * note, tests): key "g3" = the large matrix products of this batch run on operand images (gemm3.hip),
+ * "g3_model" = the weights workspace holds the k16 weight images (a property of the MODEL and the knobs only:
+ * the weights layout never moves with the batch), "g3_tn" = the four large weight gradients run on images,
+ * "g3_lstm" = the fused LSTM launch does, "small_r" = the small-batch tile plans are selected.  *value = 0 / 1. */
+int marl_plan_query(const marl_config* cfg, int train, const char* key, int* value);
+
 #ifdef __cplusplus
 }
 #endif

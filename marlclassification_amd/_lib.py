@@ -71,7 +71,7 @@ EXPORTS = (
     "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_tune_get marl_draw_episode "
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
     "marl_graph_destroy marl_image_bytes marl_image_build marl_gemm_nt_images marl_gemm_nt_images_batch "
-    "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch"
+    "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch marl_plan_query"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -134,6 +134,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_profile_begin.argtypes = [_i, _i]
     lib.marl_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(_i)]
     lib.marl_debug_buffer.argtypes = [_cfgp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]
+    lib.marl_plan_query.argtypes = [_cfgp, _i, C.c_char_p, C.POINTER(_i)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("marl_abi_version", "marl_tune_get"):

@@ -207,10 +207,16 @@ struct WLayout {
 // Measured: a gain from cells of >= 128 units on (C3 -1.8 %, C4 -4.8 % per iteration);
 // the 64-unit MNIST shapes lose 4 % to the image writes, so they keep the fp32-operand kernels unless the
 // knob g3_min_units is lowered (the parity fixtures do that to run this path on small shapes too).
-static bool g3_enabled(const Dims& d) {
+// The MODEL-only part decides the weights workspace (its k16 weight images): that layout must not move
+// with the batch - an epoch's last partial batch or an odd eval batch runs on the weights packed for the
+// previous one.  The batch-dependent part only picks the kernels of a call.
+static bool g3_model_ok(const Dims& d) {
     const int mu = tune_get("g3_min_units", 128);
-    return split_mode() && tune_get("g3", 1) != 0 && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32) &&
-           (d.n_b & 3) == 0 && (d.n_a & 3) == 0 && d.n_b >= mu && d.n_a >= mu;
+    return split_mode() && tune_get("g3", 1) != 0 && (d.n_b & 3) == 0 && (d.n_a & 3) == 0 && d.n_b >= mu &&
+           d.n_a >= mu;
+}
+static bool g3_enabled(const Dims& d) {
+    return g3_model_ok(d) && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32);
 }
 // the four large weight gradients on images (gemm_tn3_kernel: 256-column tiles of A, whole 256 x 256 tiles
 // or column passes, g3_tn_plan): only where that form wins - >= 32768 contraction rows (at C4's 8192 rows the
@@ -238,7 +244,7 @@ static void make_wlayout(const Dims& d, WLayout& w) {
             if (m.kind == PK_MATRIX) {
                 w.wp3[i] = b.take(split_image_floats(m.n, m.k));
                 w.wt3[i] = b.take(split_image_floats(m.k, m.n));
-                if (g3_enabled(d)) {
+                if (g3_model_ok(d)) {
                     w.wp3k[i] = b.take(img_bytes(m.n, m.k) / sizeof(float));
                     w.wt3k[i] = b.take(img_bytes(m.k, m.n) / sizeof(float));
                 }
@@ -596,7 +602,10 @@ static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void
     for (int l = 0; l < c.d.L; ++l) probe.layer[l].wfrag = c.w.wf[4 * l] ? c.W + c.w.wf[4 * l] : nullptr;
     c.u3_by_producers = c.e.g3 && tune_get("g3_lstm", 1) != 0 && tune_get("g3_u3", 1) != 0 && c.e.fused_fwd &&
                         cnn_fwd_writes_image(probe) && use_panels(c.d) && !use_side_stream() &&
-                        ((c.d.nf | c.d.n_mo | c.d.n_d) & 3) == 0;
+                        ((c.d.nf | c.d.n_mo | c.d.n_d) & 3) == 0 &&
+                        // (the producers write exactly nin columns: a K pad of the last 16-deep step would be
+                        // whatever the workspace held - only the stand-alone image pass zeroes it)
+                        c.d.nin % 16 == 0;
     return MARL_OK;
 }
 
@@ -2168,6 +2177,23 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
     }
     set_error("unknown debug buffer %s", name);
     return MARL_EINVAL;
+}
+
+int marl_plan_query(const marl_config* cfg, int train, const char* key, int* value) {
+    Dims d;
+    MARL_TRY(make_dims(cfg, d));
+    (void)train;
+    if (!key || !value) return MARL_EINVAL;
+    if (!strcmp(key, "g3")) *value = g3_enabled(d);
+    else if (!strcmp(key, "g3_model")) *value = g3_model_ok(d);
+    else if (!strcmp(key, "g3_lstm")) *value = g3_enabled(d) && tune_get("g3_lstm", 1) != 0;
+    else if (!strcmp(key, "g3_tn")) *value = g3_enabled(d) && g3_tn_enabled(d);
+    else if (!strcmp(key, "small_r")) *value = 0;
+    else {
+        set_error("unknown plan key %s", key);
+        return MARL_EINVAL;
+    }
+    return MARL_OK;
 }
 
 }  // extern "C"

@@ -945,7 +945,7 @@ int marl_image_build(const float* src, int ld, int64_t rows, int k, void* image,
 int marl_gemm_nt_images(const void* a3, const void* b3, const float* bias, float* c, int ldc, int m, int n,
                         int k, int accumulate, int variant, void* stream) {
     using namespace marl;
-    if (k < 1) return MARL_EINVAL;
+    if (k < 1 || m < 1 || n < 1 || !a3 || !b3 || !c || ldc < n) return MARL_EINVAL;
     G3Batch bt{};
     bt.p[0] = g3_prob(a3, 0, b3, 0, k, c, ldc, m, n, bias, accumulate);
     bt.count = 1;
@@ -957,7 +957,10 @@ int marl_gemm_nt_images_batch(int count, const void* const* a3, const void* cons
                               const int* n, const int* ldc, int m, int k, int accumulate, int variant,
                               void* stream) {
     using namespace marl;
-    if (count < 1 || count > kMaxG3 || k < 1 || !a3 || !b3 || !c || !n || !ldc) return MARL_EINVAL;
+    if (count < 1 || count > kMaxG3 || k < 1 || m < 1 || !a3 || !b3 || !c || !n || !ldc)
+        return MARL_EINVAL;
+    for (int i = 0; i < count; ++i)
+        if (n[i] < 1 || ldc[i] < n[i] || !a3[i] || !b3[i] || !c[i]) return MARL_EINVAL;
     G3Batch bt{};
     for (int i = 0; i < count; ++i)
         bt.p[i] = g3_prob(a3[i], 0, b3[i], 0, k, c[i], ldc[i], m, n[i], nullptr, accumulate);
@@ -972,7 +975,7 @@ int marl_lstm_images(const void* u3, int nin, const void* h3, const void* wih3, 
                      void* h3_next, int m, int n, int ld_state, int ld_gates, int variant, int cells,
                      void* stream) {
     using namespace marl;
-    if (nin < 1 || n < 1) return MARL_EINVAL;
+    if (nin < 1 || n < 1 || m < 1 || !u3 || !h3 || !wih3 || !whh3) return MARL_EINVAL;
     G3Batch bt{};
     G3Prob& p = bt.p[0];
     p = g3_prob(u3, 0, wih3, 0, nin, nullptr, 0, m, n, bias);
@@ -996,10 +999,18 @@ int marl_lstm_images(const void* u3, int nin, const void* h3, const void* wih3, 
 
 // C[NI,NJ] = sum_r A[r,i] B[r,j] from images whose rows are the contraction index (rows % 32 == 0);
 // colsum (nullable) [NI] = column sums of A; scratch >= marl_gemm_tn_images_scratch() bytes
-size_t marl_gemm_tn_images_scratch(int ni, int nj, int64_t rows) { return marl::g3_tn_scratch_bytes(ni, nj, rows); }
+size_t marl_gemm_tn_images_scratch(int ni, int nj, int64_t rows) {
+    if (ni < 1 || nj < 1 || rows < 32 || rows % 32 != 0) return 0;  // (the plan divides by the tile count)
+    return marl::g3_tn_scratch_bytes(ni, nj, rows);
+}
 int marl_gemm_tn_images(const void* a3, const void* b3, float* c, int ldc, int ni, int nj, int64_t rows,
                         float* colsum, float* scratch, size_t scratch_bytes, void* stream) {
     using namespace marl;
+    if (ni < 1 || nj < 1 || rows < 32 || rows % 32 != 0 || !a3 || !b3 || !c) {
+        set_error("gemm_tn_images: ni=%d nj=%d rows=%lld (rows must be a positive multiple of 32)", ni, nj,
+                  (long long)rows);
+        return MARL_EINVAL;
+    }
     if (!scratch || scratch_bytes < g3_tn_scratch_bytes(ni, nj, rows)) {
         set_error("gemm_tn_images: scratch too small");
         return MARL_ESIZE;

@@ -180,6 +180,11 @@ class HipEngine:
             raise RuntimeError("HipEngine needs a GPU device (torch 'cuda' == HIP on ROCm)")
         self.slots = state_dict_slots(spec.n_cnn_layers)
         self._wws: Optional[th.Tensor] = None
+        self._wws_epoch = _tune_epoch   # tune epoch the weights workspace was laid out under
+        self._wws_bytes = 0
+        # bumped whenever the weights workspace is (re)allocated: its packed copies are gone and whoever
+        # packed last (FusedA2C, ModelsWrapper.ensure_packed) must pack again before the next call
+        self.weights_generation = 0
         self._ews: Dict[Tuple, th.Tensor] = {}
         self._cfg_key: Optional[Tuple] = None
         self.cfg: Optional[MarlConfig] = None
@@ -202,6 +207,11 @@ class HipEngine:
             c, h, w = img_shape
             self.cfg = self.spec.config(nb_agents, batch, nb_steps, c, h, w, img_u8)
             self._cfg_key = key
+            # The weights layout is a function of the MODEL and the knobs only (csrc/episode.hip,
+            # g3_model_ok) - belt and braces: should a configuration ever ask for another size, the packed
+            # copies of the old layout must not be read through the new one.
+            if self._wws is not None and self._sizes(True)[0] != self._wws_bytes:
+                self._wws = None
         assert self.cfg is not None
         return self.cfg
 
@@ -211,10 +221,23 @@ class HipEngine:
         return wb.value, eb.value
 
     def weights_ws(self) -> th.Tensor:
+        if self._wws is not None and self._wws_epoch != _tune_epoch:
+            # a knob moved (g3, g3_min_units, mfma_split ... decide which weight images exist): the old
+            # buffer has the old layout AND the old contents - drop it, and make every packer pack again
+            self._wws = None
         if self._wws is None:
             wb, _ = self._sizes(True)
             self._wws = th.zeros(wb // 4 + 64, dtype=th.float32, device=self.device)
+            self._wws_epoch = _tune_epoch
+            self._wws_bytes = wb
+            self.weights_generation += 1
         return self._wws
+
+    def weights_token(self) -> int:
+        """Generation of the weights workspace AFTER applying pending invalidations (callers compare it
+        with the value they saw when they last packed)."""
+        self.weights_ws()
+        return self.weights_generation
 
     def episode_ws(self, train: bool) -> th.Tensor:
         if self._tune_seen != _tune_epoch:  # a layout knob changed: sizes may have moved

@@ -118,15 +118,15 @@ class FusedA2C:
         self._pviews = flat.param_views()
         self._gviews = flat.grad_views()
         self._loss_bufs = None
-        self._packed = False
+        self._packed_gen = -1  # engine.weights_generation at the last pack (-1: never packed)
 
     def pack(self) -> None:
         self.engine.pack(self._pviews)
-        self._packed = True
+        self._packed_gen = self.engine.weights_generation
 
     def rollout(self, img: th.Tensor, draws: EpisodeDraws, train: bool,
                 forced_actions: Optional[th.Tensor] = None) -> EpisodeTensors:
-        if not self._packed:
+        if self._packed_gen != self.engine.weights_token():  # never packed, or the workspace was re-laid-out
             self.pack()
         return self.engine.episode_forward(img, draws.pos0, draws.h0, draws.c0, draws.hc0,
                                            draws.cc0, draws.noise, forced_actions, train,

@@ -179,7 +179,7 @@ class ModelsWrapper(nn.Module):
         """Refresh the engine's padded / transposed weight copies if any parameter changed
         through torch (load_state_dict, an optimiser, manual edits)."""
         flat = self.flat_state()
-        token = self._version_token()
+        token = self._version_token() + (eng.weights_token(),)
         if self.__packed_token.get(id(eng)) != token:
             eng.pack(flat.param_views())
             self.__packed_token[id(eng)] = token
@@ -187,4 +187,4 @@ class ModelsWrapper(nn.Module):
     def mark_updated(self, eng: HipEngine) -> None:
         """Called after the HIP Adam kernel wrote the flat buffer (no torch version bump)."""
         eng.pack(self.flat_state().param_views())
-        self.__packed_token = {id(eng): self._version_token()}
+        self.__packed_token = {id(eng): self._version_token() + (eng.weights_token(),)}

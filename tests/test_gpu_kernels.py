@@ -229,7 +229,10 @@ def _image(lib, check, device, t, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(96, 256, 160), (665, 92, 183), (37, 45, 24), (4096, 512, 368),
-                                   (3000, 130, 7), (300, 2048, 624), (8192 + 77, 368, 200)])
+                                   (3000, 130, 7), (300, 2048, 624), (8192 + 77, 368, 200),
+                                   # the shapes of tools/g3_lab.py (a stale lab record showed wrong
+                                   # results on exactly these, under forced variants, and no test covered them)
+                                   (4096, 256, 1024), (65536, 384, 256), (4096, 1024, 624)])
 @pytest.mark.parametrize("variant", [1, 2, 3], ids=["256x128", "128x128", "128x64"])
 @pytest.mark.parametrize("acc", [0, 1])
 def test_gemm_nt_images(device, m, n, k, variant, acc):
@@ -274,7 +277,7 @@ def test_gemm_nt_images_six_products_kat(device):
         assert th.equal(cd.cpu().double(), want)
 
 
-@pytest.mark.parametrize("m,n,nin", [(4096, 256, 368), (777, 23, 45), (96, 64, 96), (300, 80, 200)])
+@pytest.mark.parametrize("m,n,nin", [(4096, 256, 368), (777, 23, 45), (96, 64, 96), (300, 80, 200), (512, 256, 624)])
 @pytest.mark.parametrize("variant", [1, 2], ids=["256rows", "128rows"])
 def test_lstm_images(device, m, n, nin, variant):
     """fused cell (networks/recurrent.py:19-35) from images against float64, and the image of h' it writes

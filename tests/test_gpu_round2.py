@@ -485,7 +485,7 @@ def test_two_rank_hip_trainer_matches_big_batch_update(device, exact):
 # ---- achieved errors per fixture (recorded for DESIGN.md) ------------------------------------------
 def test_record_achieved_errors(device):
     """Not a tolerance test: measures the achieved max |error| of every fixture against the
-    reference's goldens and writes them to gpurun_out/r03_achieved_errors.json (with the
+    reference's goldens and writes them to gpurun_out/r05_achieved_errors.json (with the
     sampled-index flips of the oracle-only cases that ran before it in this session)."""
     rec = {}
     for tag in ("g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt", "g4_resisc_b2"):
@@ -521,12 +521,14 @@ def test_record_achieved_errors(device):
     rec["oracle_only_free_running"] = {"cases": len(FLIPS), "samples": sum(f["numel"] for f in FLIPS),
                                        "flips": sum(f["flips"] for f in FLIPS),
                                        "budget": sum(f["allowed"] for f in FLIPS)}
-    path = os.path.join(ROOT, "gpurun_out")
-    try:
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "r03_achieved_errors.json"), "w") as f:
-            json.dump(rec, f, indent=1)
-    except OSError:
-        pass
+    # margin to every tolerance (tolerance / achieved: > 1 passes; VERDICT r4: the thinnest one is tracked per round)
+    tol = {"preds_abs": 1e-5, "logp_abs": 1e-5, "values_abs": 1e-5, "grad_rel_max": 1e-4, "adam_update_err_over_lr": 1e-3}
+    for tag, e in rec.items():
+        if "preds_abs" in e:
+            e["margin"] = {k: (tol[k] / e[k] if e[k] > 0 else float("inf")) for k in tol if k in e}
+    rec["thinnest_margin"] = min(m for e in rec.values() if "margin" in e for m in e["margin"].values())
+    from tests.util import record
+
+    record("achieved_errors", rec)
     print(json.dumps(rec))
-    assert all(r["pos_equal"] for r in rec.values() if "pos_equal" in r)
+    assert all(r["pos_equal"] for r in rec.values() if isinstance(r, dict) and "pos_equal" in r)

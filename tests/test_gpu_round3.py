@@ -115,9 +115,10 @@ def test_full_gradient_at_benched_size_matches_oracle(device):
             bad[k] = (err, scale)
     assert not bad, bad
     assert n > 1_600_000
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_full_gradient.json"), "w") as f:
-        json.dump({"entries": n, "max_err_over_tensor_scale": worst, "batch": nb}, f)
+    from tests.util import record
+
+    record("full_gradient", {"entries": n, "max_err_over_tensor_scale": worst, "tolerance": 1e-4,
+                             "margin": 1e-4 / worst if worst > 0 else None, "batch": nb})
 
 
 # ---- (d) BASELINE.json's full sizes: properties the domain offers ----------------------------------
@@ -221,7 +222,7 @@ def test_graph_replay_survives_eager_iterations_and_lr_changes(device):
 def test_png_folder_loader_rate(device, tmp_path):
     """Trains from a generated PNG folder at 256 x 256 and measures what the loader sustains
     (images / s decoded + uploaded, one rank) next to what one training step consumes; the
-    numbers go to gpurun_out/r04_loader.json (DESIGN.md quotes them)."""
+    numbers go to gpurun_out/r05_loader.json (DESIGN.md quotes them)."""
     import numpy as np
     from PIL import Image
     from torch.utils.data import DataLoader
@@ -293,7 +294,7 @@ def test_png_folder_loader_rate(device, tmp_path):
     assert th.equal(first[0][0][0].cpu(), ds[idx0[0]][0]) and first[0][1][0].item() == ds[idx0[0]][1].item()
     rec["cpu_count"] = os.cpu_count()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_loader.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r05_loader.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
     # more decode processes must not be slower than the training thread decoding alone

@@ -1,0 +1,210 @@
+"""GPU, round 5: (a) full-size parity on DISTINCT images (the tiled-replica tests of rounds 2-4 are
+blind to cross-image indexing - every replica held the same images, states and noise), (b) the weights workspace
+layout does not move with the batch, (c) a layout knob invalidates the weights workspace and makes
+every packer pack again.  Everything goes through the C ABI."""
+import ctypes as C
+
+import pytest
+import torch as th
+
+from oracle import marl_oracle as mo
+from tests.util import Golden, model_spec, record, uniform_params
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+C3_CFG = mo.OracleConfig("resisc45", 12, 256, 256, 64, 96, 16, 45, 384, 384)
+C4_CFG = mo.OracleConfig("aid", 24, 256, 256, 64, 96, 16, 30, 320, 320, actions=[[3, 0], [-3, 0], [0, 3], [0, -3]])
+C5_CFG = mo.OracleConfig("aid", 32, 256, 256, 64, 96, 16, 45, 384, 384, actions=[[4, 0], [-4, 0], [0, 4], [0, -4]])
+
+# tag: (config, agents, DISTINCT images, steps, image shape, copies of each image) -> batch = images * copies
+DISTINCT = {
+    "c3_resisc_b256": (C3_CFG, 16, 16, 16, (3, 256, 256), 16),   # BASELINE configs[2] as benched: R = 4096
+    "c4_aid_b32": (C4_CFG, 16, 8, 16, (3, 600, 600), 4),        # configs[3] at 32 images per GPU: R = 512
+    "c5_synth_b32": (C5_CFG, 64, 4, 32, (3, 1024, 1024), 8),   # configs[4] at 32 per GPU: R = 2048, 64 agents
+}
+
+
+def _engine(cfg, device, na, nb, ns, shape, params):
+    from marlclassification_amd.engine import HipEngine
+
+    eng = HipEngine(model_spec(cfg), device)
+    eng.configure(na, nb, ns, shape)
+    eng.pack({k: v.to(device) for k, v in params.items()})
+    return eng
+
+
+@pytest.mark.parametrize("tag", list(DISTINCT))
+def test_full_size_parity_on_distinct_shuffled_images(device, tag):
+    """`nd` DIFFERENT oracle images (own pixels, start positions, initial states, sampling noise, labels) are laid
+    out `rep` times each in a SHUFFLED order along the batch, up to the benched batch size.  Every slot must
+    reproduce the oracle's trajectory of ITS source image - positions bit for bit (teacher-forced to the oracle's
+    actions), logits / log-probs / values within 1e-5 - so a kernel that reads image b +- k, averages the messages
+    of a neighbouring image's agents or mixes rows across a tile boundary fails here (its neighbours are other
+    images), which the identical-replica tests of rounds 2-4 could not see.  With the oracle batch's advantage
+    statistics (loss phase 2) the big batch's gradient is the oracle's: every entry within 1e-4 of its tensor's
+    scale.  The size-dependent plans (column-pass / 256 x 256 row contractions, 256 x 128 NT tiles, two-launch
+    panels at 64 agents, split-K slab counts, small-R tile plans) all run on this data."""
+    cfg, na, nd, ns, shape, rep = DISTINCT[tag]
+    params = uniform_params(cfg, 7)
+    img = th.rand(nd, *shape, generator=th.Generator().manual_seed(21))
+    y = th.randint(0, cfg.nb_class, (nd,), generator=th.Generator().manual_seed(22))
+    inp = mo.draw_episode_inputs(cfg, na, nd, ns, shape[1:], 23)
+    tr, lo, grads = mo.train_iteration(params, cfg, img, y, inp, ns, 0.99)
+
+    small = [t.to(device) for t in (inp.pos0, inp.h0, inp.c0, inp.hc0, inp.cc0, inp.q)]
+    eng1 = _engine(cfg, device, na, nd, ns, shape, params)
+    out1 = eng1.episode_forward(img.to(device), *small, tr.step_actions.to(device), True)
+    stats = eng1.a2c_loss(out1, y.to(device), 0.99, phase=1)[4].clone()
+    del eng1, out1
+
+    nb = nd * rep
+    src = th.arange(nd).repeat(rep)[th.randperm(nb, generator=th.Generator().manual_seed(24))]  # slot -> source image
+    assert all(int((src == s).sum()) == rep for s in range(nd)) and not th.equal(src, th.arange(nd).repeat(rep))
+    pick = lambda t, dim: t.index_select(dim, src)  # noqa: E731
+    eng = _engine(cfg, device, na, nb, ns, shape, params)
+    big = [pick(inp.pos0, 1), pick(inp.h0, 1), pick(inp.c0, 1), pick(inp.hc0, 1), pick(inp.cc0, 1), pick(inp.q, 2)]
+    out = eng.episode_forward(pick(img, 0).to(device), *[t.to(device) for t in big],
+                              pick(tr.step_actions, 2).to(device), True)
+    assert th.equal(out.step_pos.cpu(), pick(tr.step_pos, 2)), "a slot's positions differ from its source image's"
+    errs = {}
+    for name, got, ref in (("preds", out.step_preds, tr.step_preds), ("logp", out.step_log_probas, tr.step_log_probas),
+                           ("values", out.step_values, tr.step_values)):
+        errs[name] = (got.cpu().double() - pick(ref.detach(), 2).double()).abs().max().item()
+        assert errs[name] <= ATOL, (name, errs[name])
+    # copies of one source image are bit-identical wherever they sit in the batch
+    first = [int((src == s).nonzero()[0]) for s in range(nd)]
+    for name in ("step_preds", "step_log_probas", "step_values"):
+        t = getattr(out, name).cpu()
+        assert th.equal(t, t.index_select(2, th.tensor(first)).index_select(2, src)), f"{name}: copies differ"
+    yb = pick(y, 0).to(device)
+    bufs = eng.a2c_loss(out, yb, 0.99, phase=1)
+    assert th.allclose(bufs[4], stats * rep, rtol=1e-9), (bufs[4], stats * rep)
+    bufs[4].copy_(stats)  # standardize with the oracle batch's own n / sum / sum of squares
+    gp, gl, gv, sc, _ = eng.a2c_loss(out, yb, 0.99, phase=2, bufs=bufs)
+    assert abs(sc[0].item() - lo.loss.item()) <= 5e-5 * max(1.0, abs(lo.loss.item()))
+    g_out = {k: th.zeros_like(v, device=device) for k, v in params.items()}
+    eng.episode_backward(gp, gl, gv, g_out)
+    bad, worst, n = {}, 0.0, 0
+    for k, ref in grads.items():
+        err = (g_out[k].cpu().double() - ref.double()).abs().max().item()
+        scale = ref.abs().max().item()
+        n += ref.numel()
+        worst = max(worst, err / scale if scale > 1e-12 else 0.0)
+        if not err <= 1e-4 * scale + 1e-7:
+            bad[k.replace("_ModelsWrapper__", "")] = "%.2e/%.2e" % (err, scale)
+    assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
+    record(f"distinct_{tag}", {"batch": nb, "distinct_images": nd, "rows": na * nb, "positions_equal": True,
+                               "abs_err": errs, "abs_tolerance": ATOL,
+                               "gradient_entries": n, "grad_max_err_over_tensor_scale": worst, "grad_tolerance": 1e-4,
+                               "margin": {"outputs": ATOL / max(errs.values()), "gradient": 1e-4 / max(worst, 1e-30)}})
+
+
+# ---- weights workspace: batch-independent layout, invalidated by layout knobs -------------------------
+def _slice_case(g, nb):
+    i = g.inp
+    return (g.img[:nb], mo.EpisodeInputs(i.pos0[:, :nb].contiguous(), i.h0[:, :nb].contiguous(),
+                                         i.c0[:, :nb].contiguous(), i.hc0[:, :nb].contiguous(),
+                                         i.cc0[:, :nb].contiguous(), i.q[:, :, :nb].contiguous()))
+
+
+def _run(eng, g, device, nb, train=True):
+    img, i = _slice_case(g, nb)
+    eng.configure(g.na, nb, g.ns, g.img.shape[1:])
+    out = eng.episode_forward(img.to(device), i.pos0.to(device), i.h0.to(device), i.c0.to(device), i.hc0.to(device),
+                              i.cc0.to(device), i.q.to(device), None, train)
+    gp, gl, gv, sc, _ = eng.a2c_loss(out, g.y[:nb].to(device), g.gamma)
+    grads = {k: th.zeros_like(v, device=device) for k, v in g.params.items()}
+    eng.episode_backward(gp, gl, gv, grads)
+    return out, {k: v.cpu() for k, v in grads.items()}
+
+
+@pytest.mark.parametrize("order", [(2, 1, 2), (1, 2, 1)])
+def test_weights_layout_does_not_move_with_the_batch(device, order):
+    """with 16 agents, batch 2 gives R = 32 rows (image GEMMs on), batch 1 gives R = 16 (off).
+    The weights workspace used to reserve the k16 weight images only in the first case, so every later parameter's
+    packed copy moved with the batch: an epoch's last partial batch read weights packed in the other layout
+    (silently wrong), or - in the opposite order - every call failed with MARL_ESIZE.  One engine, ONE pack, batches
+    alternating without an optimiser step: each run must equal a fresh engine packed for that batch, bit for bit."""
+    from marlclassification_amd import _lib
+    from marlclassification_amd.engine import HipEngine
+
+    g = Golden("g4_resisc_b2")
+    params = {k: v.to(device) for k, v in g.params.items()}
+    offs = {}
+    eng = HipEngine(model_spec(g.cfg), device)
+    eng.configure(g.na, order[0], g.ns, g.img.shape[1:])
+    eng.pack(params)
+    for nb in order:
+        out, grads = _run(eng, g, device, nb)
+        fresh = HipEngine(model_spec(g.cfg), device)
+        fresh.configure(g.na, nb, g.ns, g.img.shape[1:])
+        fresh.pack(params)
+        ref_out, ref_grads = _run(fresh, g, device, nb)
+        for name in ("step_pos", "step_actions", "step_preds", "step_log_probas", "step_values"):
+            assert th.equal(getattr(out, name), getattr(ref_out, name)), (nb, name)
+        for k in grads:
+            assert th.equal(grads[k], ref_grads[k]), (nb, k)
+        wb, eb = eng._sizes(True)
+        o = []
+        for idx in (_lib.P["LB_WIH"], _lib.P["POL_W0"], _lib.P["PRE_W1"]):
+            off, ld = C.c_int64(0), C.c_int(0)
+            _lib.check(eng.lib.marl_debug_buffer(C.byref(eng.cfg), 1, f"WP{idx}".encode(), 0, C.byref(off), C.byref(ld)))
+            o.append(off.value)
+        offs[nb] = (wb, tuple(o))
+        v = C.c_int(0)
+        _lib.check(eng.lib.marl_plan_query(C.byref(eng.cfg), 1, b"g3", C.byref(v)))
+        assert v.value == (1 if nb == 2 else 0)  # (the two batches really are on different kernel families)
+        _lib.check(eng.lib.marl_plan_query(C.byref(eng.cfg), 1, b"g3_model", C.byref(v)))
+        assert v.value == 1
+    assert offs[1] == offs[2], offs
+    assert eng.weights_generation == 1, "the weights workspace was re-allocated between batches"
+
+
+def test_layout_knob_invalidates_the_weights_workspace(device):
+    """engine.tune() of a knob that decides which weight images exist (g3, g3_min_units,
+    mfma_split) must drop the cached weights workspace too, and FusedA2C / ModelsWrapper.ensure_packed must pack
+    again - the old buffer has the old layout and the old size."""
+    from marlclassification_amd import engine as E
+    from marlclassification_amd.fused import EpisodeDraws, FlatParams, FusedA2C
+
+    g = Golden("g4_resisc_b2")
+    eng = E.HipEngine(model_spec(g.cfg), device)
+    eng.configure(g.na, g.nb, g.ns, g.img.shape[1:])
+    flat = FlatParams({k: tuple(v.shape) for k, v in g.params.items()}, device)
+    flat.load(g.params)
+    fa = FusedA2C(eng, flat, g.lr, g.gamma)
+    i = g.inp
+    draws = EpisodeDraws(*(t.to(device) for t in (i.pos0, i.h0, i.c0, i.hc0, i.cc0, i.q)))
+    img = g.img.to(device)
+    try:
+        ref = fa.rollout(img, draws, False)
+        gen0, size0 = eng.weights_generation, eng.weights_ws().numel()
+        E.tune("g3", 0)  # no weight images any more: smaller workspace, every later offset moves
+        out = fa.rollout(img, draws, False)  # (must re-pack by itself)
+        assert eng.weights_generation == gen0 + 1 and eng.weights_ws().numel() < size0
+        assert th.equal(out.step_pos, ref.step_pos) and th.equal(out.step_actions, ref.step_actions)
+        assert (out.step_preds - ref.step_preds).abs().max().item() <= 2e-5
+        E.tune("g3", 1)  # ... and back: the workspace grows again (the old one would be MARL_ESIZE)
+        out = fa.rollout(img, draws, False)
+        assert eng.weights_generation == gen0 + 2 and eng.weights_ws().numel() == size0
+        for name in ("step_pos", "step_actions", "step_preds", "step_log_probas", "step_values"):
+            assert th.equal(getattr(out, name), getattr(ref, name)), name
+    finally:
+        E.tune("g3", 1)
+
+
+def test_image_entry_points_refuse_empty_shapes(device):
+    """ni / nj / rows <= 0 used to reach the split plan's division by the tile count (SIGFPE)."""
+    from marlclassification_amd import _lib
+
+    lib = _lib.load()
+    assert lib.marl_gemm_tn_images_scratch(0, 16, 64) == 0 and lib.marl_gemm_tn_images_scratch(16, 0, 64) == 0
+    assert lib.marl_gemm_tn_images_scratch(16, 16, 0) == 0 and lib.marl_gemm_tn_images_scratch(16, 16, 33) == 0
+    buf = th.zeros(1024, device=device)
+    p = buf.data_ptr()
+    assert lib.marl_gemm_tn_images(p, p, p, 16, 0, 16, 64, None, p, 4096, None) == -1
+    assert lib.marl_gemm_tn_images(p, p, p, 16, 16, 16, 0, None, p, 4096, None) == -1
+    assert lib.marl_gemm_nt_images(p, p, None, p, 16, 0, 16, 16, 0, 0, None) == -1
+    assert lib.marl_gemm_nt_images(p, p, None, p, 16, 32, 0, 16, 0, 0, None) == -1

@@ -8,6 +8,22 @@ import torch as th
 from oracle import marl_oracle as mo
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = "r05"  # prefix of the parity records the GPU tests write (copied into profiles/ after the box run)
+
+
+def record(name, obj):
+    """Achieved-error / margin records of the GPU parity tests -> gpurun_out/<ROUND>_<name>.json (gpurun_out/ is
+    what comes back from the GPU box; tools/round_profiles.sh copies these into profiles/)."""
+    import json
+
+    path = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, f"{ROUND}_{name}.json"), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
 
 CASES = {
     "g1_conftest": mo.OracleConfig("mnist", 12, 23, 22, 21, 20, 19, 10, 24, 25),

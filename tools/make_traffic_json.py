@@ -3,7 +3,7 @@ launch of every kernel class of marl_profile_begin, = 2 x FETCH_SIZE (gfx950 cor
 coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KB.  The file is
 stamped with the sha256 of csrc/*.hip|*.h at profiling time; bench.py only quotes it while the
 sources it runs still hash to that value.
-usage: python tools/make_traffic_json.py r04"""
+usage: python tools/make_traffic_json.py r05"""
 import csv
 import json
 import os
@@ -17,7 +17,8 @@ CLASS_OF = [("gemm_nt3_kernel<128, 128, 4, 1, 3, true", 0), ("gemm_nt3_kernel<25
             ("gemm_nt3_kernel", 1), ("gemm_tn3_kernel", 2), ("gemm_tn_batch_kernel", 2),
             ("gemm_nt_kernel<128, 128, 4, 1, true", 0), ("gemm_nt_split_kernel<128, true", 0),
             ("gemm_nt_kernel", 1), ("gemm_nt_split_kernel", 1), ("gemm_tn_kernel", 2),
-            ("gemm_tn_split_kernel", 2), ("cnn_fwd", 3), ("panel_", 4), ("cnn_dgrad", 5), ("cnn_wgrad", 5),
+            ("gemm_tn_split_kernel", 2), ("gemm_tn", 2),  # (any other row-contraction form: gemm_tn3_passes_kernel ...)
+            ("gemm_nt", 1), ("cnn_fwd", 3), ("panel_", 4), ("cnn_dgrad", 5), ("cnn_wgrad", 5),
             ("cnn_bwd", 5)]
 
 
@@ -30,6 +31,8 @@ F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
 out = {}
 for k, (calls, f) in F.items():
     cls = next((c for p, c in CLASS_OF if k.startswith(p)), None)
+    if cls is None and k.startswith("gemm"):  # (a GEMM kernel outside every class under-reports one)
+        raise SystemExit(f"make_traffic_json: GEMM kernel {k[:80]} matches no class prefix")
     if cls is None or k not in W:
         continue
     e = out.setdefault(str(cls), {"launches": 0, "fetch_kb": 0.0, "write_kb": 0.0, "kernels": []})

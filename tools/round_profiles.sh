@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box): R=r04 bash tools/round_profiles.sh
+# usage (on the GPU box): R=r05 bash tools/round_profiles.sh
 # Everything profiles/ holds for a round, from one box:
 #   kernel trace (+ --stats-equivalent summary) of the default bench command  -> ${R}_bench_c3_kernel_stats.csv
 #   separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, waits, LDS, insts)
 #   ${R}_traffic.json stamped with the sha256 of csrc/*.hip|*.h (tools/make_traffic_json.py)
 #   un-profiled bench lines: c3 (with the CPU leg), rollout-only, c2 / c4 / c5 (+ their kernel stats)
-R=${R:-r04}
+R=${R:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 P=profiles
@@ -40,6 +40,20 @@ for c in c2 c4 c5; do
   prof $c --config $c --steps 10 --warmup 3
 done
 prof c3_rollout_only --rollout-only --steps 10 --warmup 3
+# the kernel-level lab records, regenerated from THIS tree (a stale one was cited as proof)
+python3 tools/g3_lab.py > gpurun_out/${R}_g3_lab.log 2>&1 && cp gpurun_out/g3_lab.json $P/${R}_g3_lab.json
+python3 - <<PY
+import json
+rows = json.load(open("$P/${R}_g3_lab.json"))
+bad = [r for r in rows if r.get("max_err", 0) > 1e-3 or r.get("err_h", 0) > 1e-4 or r.get("err_c", 0) > 1e-4
+       or r.get("pipelined_eq_safe") is False or r.get("h_image_ok") is False]
+print("g3_lab rows:", len(rows), "bad:", bad)
+assert not bad
+PY
+# parity records written by the GPU tests (tests/util.record) -> profiles/
+for f in gpurun_out/${R}_achieved_errors.json gpurun_out/${R}_full_gradient.json gpurun_out/${R}_distinct_*.json gpurun_out/gemm_errors.json; do
+  [ -f $f ] && cp $f $P/$(basename $f | sed "s/^gemm_errors/${R}_gemm_errors/")
+done
 cp -r $P gpurun_out/profiles_$R
 for f in $P/${R}_bench_c3.json $P/${R}_bench_c3_rollout_only.json $P/${R}_bench_c2.json $P/${R}_bench_c4.json $P/${R}_bench_c5.json; do cut -c1-260 $f; done
 head -12 $P/${R}_bench_c3_kernel_stats.csv
