@@ -2188,7 +2188,10 @@ int marl_plan_query(const marl_config* cfg, int train, const char* key, int* val
     else if (!strcmp(key, "g3_model")) *value = g3_model_ok(d);
     else if (!strcmp(key, "g3_lstm")) *value = g3_enabled(d) && tune_get("g3_lstm", 1) != 0;
     else if (!strcmp(key, "g3_tn")) *value = g3_enabled(d) && g3_tn_enabled(d);
-    else if (!strcmp(key, "small_r")) *value = 0;
+    else if (!strcmp(key, "small_r")) {  // the gate-split LSTM plans (gemm3.hip, g3_lstm_plan): tiles of 128 rows < 192
+        const int64_t t128 = cdiv(d.R, 128) * (cdiv(d.n_b, 32) + cdiv(d.n_a, 32));
+        *value = g3_enabled(d) && tune_get("g3_lstm", 1) != 0 && t128 < tune_get("g3_lstm_small_tiles", 192);
+    }
     else {
         set_error("unknown plan key %s", key);
         return MARL_EINVAL;

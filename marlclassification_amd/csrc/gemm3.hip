@@ -52,7 +52,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
     // the A_INS + B_INS instructions of a step are dealt round robin: wave w issues t = w + NW i
     constexpr int T_INS = A_INS + B_INS, NI_LO = T_INS / NW, NI_HI = (T_INS + NW - 1) / NW;
     constexpr int I_EXTRA = T_INS % NW;  // waves [0, I_EXTRA) issue NI_HI instructions
-    static_assert(!LSTM || (BN == 128 && WN == 1), "LSTM tile = 4 gates x 32 units per wave");
+    // LSTM tile = 4 gates x 32 units: all four gates in one wave (WN == 1: a lane holds the gates of its
+    // elements) or one gate per wave (WN == 4, "gate split": the small-batch plans - a wave's MFMA chain is a
+    // quarter as long and a 32-row tile spreads over the four SIMDs of its CU; the gates meet in LDS)
+    static_assert(!LSTM || (BN == 128 && (WN == 1 || WN == 4)), "LSTM tile = 4 gates x 32 units");
 
     // ABL (perf diagnosis only): 0 product build, 1 every step fully waited for (SAFE), 2 no LDS-DMA in
     // the loop, 3 no MFMA, 4 block-major source addresses (1 KB contiguous per instruction; wrong data),
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                          \
         hp[((r & 3) + 8 * (r >> 2) + row_h) * HLD + col_l] = (val_);
 #define G3_PANEL_GET(q_) (*reinterpret_cast<const float4*>(hp + (tr + 8 * (q_)) * HLD + tc))
-    if (!LSTM) {
+    if constexpr (!LSTM) {
         const bool vec = (P.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(P.c) & 15) == 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -276,6 +279,99 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
                 }
                 wait_lgkm0();  // (the panel is rewritten by the next block)
             }
+    } else if constexpr (WN == 4) {
+        // ---- gate split: acc[0][0] of wave (wm, g = wn) = pre-activations of gate g, rows m0 + 32 wm ..,
+        // units n0 ..  Same arithmetic, in the same order, as the one-wave form below (bit-identical results).
+        const int g = wn;
+        const int unit = n0 + col_l;
+        const int uc = unit < N ? unit : N - 1;
+        const float bg_ = P.bias[g * N + uc];
+        if (g == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = tanh_fast(acc[0][0][r] + bg_);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = sigmoid_acc(acc[0][0][r] + bg_);
+        }
+        G3_PANEL_PUT(acc[0][0][r])  // panel `wave` = (row group wm, gate g)
+        __syncthreads();
+        // the 256 threads of a row group share its 32 x 32 (row, unit) elements: four consecutive units each
+        const int t = wn * 64 + lane, er = t >> 3, ec = (t & 7) * 4;
+        const float* gpn = reinterpret_cast<const float*>(sm) + (wm * 4) * 32 * HLD + er * HLD + ec;
+        const float4 vi = *reinterpret_cast<const float4*>(gpn), vf = *reinterpret_cast<const float4*>(gpn + 32 * HLD),
+                     vg = *reinterpret_cast<const float4*>(gpn + 2 * 32 * HLD),
+                     vo = *reinterpret_cast<const float4*>(gpn + 3 * 32 * HLD);
+        const int row = m0 + wm * 32 + er, col = n0 + ec;
+        const bool rok = row < M;
+        const int rowc = rok ? row : M - 1;
+        const bool svec = (P.ld_state & 3) == 0;
+        const bool col_ok = col < ((N + 3) & ~3);
+        float cp[4];
+        if (svec && col_ok) {
+            const float4 c4 = *reinterpret_cast<const float4*>(P.c_prev + (size_t)rowc * P.ld_state + col);
+            cp[0] = c4.x, cp[1] = c4.y, cp[2] = c4.z, cp[3] = c4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cp[e] = P.c_prev[(size_t)rowc * P.ld_state + (col + e < N ? col + e : N - 1)];
+        }
+        const float gi4[4] = {vi.x, vi.y, vi.z, vi.w}, gf4[4] = {vf.x, vf.y, vf.z, vf.w},
+                    gg4[4] = {vg.x, vg.y, vg.z, vg.w}, go4[4] = {vo.x, vo.y, vo.z, vo.w};
+        float cn[4], hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool uok = col + e < N;
+            const float c_ = gf4[e] * cp[e] + gi4[e] * gg4[e];
+            cn[e] = uok ? c_ : 0.f;
+            hn[e] = uok ? go4[e] * tanh_fast(c_) : 0.f;
+        }
+        // h' of the row group -> its own LDS panel (behind the gate panels) for the image stores below
+        float* hpn = reinterpret_cast<float*>(sm) + (WM * 4 + wm) * 32 * HLD;
+        *reinterpret_cast<float4*>(hpn + er * HLD + ec) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (rok) {
+            float* cdst = P.c_next + (size_t)row * P.ld_state + col;
+            float* hdst = P.h_next + (size_t)row * P.ld_state + col;
+            if (svec) {
+                if (col_ok) {
+                    *reinterpret_cast<float4*>(cdst) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+                    *reinterpret_cast<float4*>(hdst) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < N) cdst[e] = cn[e], hdst[e] = hn[e];
+            }
+            if (P.gates) {
+                const bool gvec = (N & 3) == 0 && (P.ld_gates & 3) == 0;
+                float* gd = P.gates + (size_t)row * P.ld_gates + col;
+                if (gvec) {
+                    if (col_ok) {
+                        *reinterpret_cast<float4*>(gd) = vi;
+                        *reinterpret_cast<float4*>(gd + N) = vf;
+                        *reinterpret_cast<float4*>(gd + 2 * N) = vg;
+                        *reinterpret_cast<float4*>(gd + 3 * N) = vo;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) gd[e] = gi4[e], gd[N + e] = gf4[e], gd[2 * N + e] = gg4[e], gd[3 * N + e] = go4[e];
+                }
+            }
+        }
+        if (P.h3) {
+            __syncthreads();
+            if (wn == 0) {  // one image step of one row per lane: 96 contiguous bytes
+                const int lr = lane >> 1, u0 = (lane & 1) * 16;
+                const int irow = m0 + wm * 32 + lr;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(hpn + lr * HLD + u0 + 4 * q);
+                    v[4 * q] = t4.x, v[4 * q + 1] = t4.y, v[4 * q + 2] = t4.z, v[4 * q + 3] = t4.w;
+                }
+                if (irow < M && n0 + u0 < ((N + 15) & ~15))
+                    img_store16(P.h3 + img_off((int64_t)P.h3_row0 + irow, (n0 + u0) >> 4, P.h3_steps), v);
+            }
+        }
     } else {
         // (TM == 1, TN == 4: acc[0][g] = gate g of unit n0 + col_l, 16 rows of the wave's 32)
         const int unit = n0 + col_l;
@@ -712,6 +808,7 @@ static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st
     constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
     static_assert(lds <= 160 * 1024, "LDS ring");
     static_assert((size_t)WM * WN * 32 * 36 * 4 <= lds, "epilogue panels fit the ring");
+    static_assert(!(LSTM && WN == 4) || (size_t)WM * 5 * 32 * 36 * 4 <= lds, "gate panels + h' panels fit the ring");
     const int abl = batch.safe;
 #ifdef MARL_G3_ABLATE
     static long long* d_clk = nullptr;
@@ -775,7 +872,7 @@ static int check_g3(const G3Prob& p, bool lstm) {
 }
 
 // variant: 0 = automatic, else (perf experiments) 1: 256 x 128 / 8 waves, 2: 128 x 128 / 4 waves,
-// 3: 128 x 64 / 4 waves
+// 3: 128 x 64 / 4 waves, 7: 64 x 64 / 4 waves, 11: 128 x 64 / 8 waves, 12: 64 x 64 / 4 waves with a 3-stage ring
 int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
     if (batch.count < 1 || batch.count > kMaxG3) return MARL_EINVAL;
     int max_m = 0, max_n = 0;
@@ -788,7 +885,16 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
         blocks128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 128);
     }
     if (!variant) variant = tune_get("g3_nt_variant", 0);
-    if (!variant) variant = blocks128 >= 1024 && max_n >= 96 ? 1 : (blocks128 >= 384 && max_n >= 96 ? 2 : 3);
+    if (!variant) {
+        // Tile plans by launch size (tools/small_r_lab.py, profiles/r05_small_r_lab.json; each knob overrides):
+        // big = one product with >= 1024 tiles of 128 x 128, mid = >= 256, small = everything else (the in-loop
+        // backward batch at every batch size, the narrow heads, all launches of a 32-image batch).  Wave tiles
+        // of 32 x 32 (plans 7, 11, 12: ~85 registers, 3-4 workgroups per CU) hide the ring's barriers better than
+        // 64 x 64 ones wherever the launch is not long enough to amortise a 12 us prologue + epilogue.
+        const int v_big = tune_get("g3_nt_v_big", 2), v_mid = tune_get("g3_nt_v_mid", 2),
+                  v_small = tune_get("g3_nt_v_small", 7);
+        variant = max_n < 96 ? v_small : blocks128 >= 1024 ? v_big : blocks128 >= tune_get("g3_nt_mid_blocks", 256) ? v_mid : v_small;
+    }
     prof_before(1, st);
     int rc;
     if (variant == 1)
@@ -803,10 +909,31 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
     else if (variant == 6)  // eight waves, 256 x 128, three stages (2 workgroups would need 216 KB: still 1 per CU)
         rc = launch_g3_variant<256, 128, 4, 2, 3, false>(batch, max_m, max_n, st);
 #endif
+    else if (variant == 7)
+        rc = launch_g3_variant<64, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
+    else if (variant == 11)
+        rc = launch_g3_variant<128, 64, 4, 2, 3, false>(batch, max_m, max_n, st);
+    else if (variant == 12)
+        rc = launch_g3_variant<64, 64, 2, 2, 3, false>(batch, max_m, max_n, st);
     else
         rc = launch_g3_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
     prof_after(1, st);
     return rc;
+}
+
+// Tile plan of the fused LSTM launch.  128 x 128 tiles (variant 2) need >= 2 workgroups per CU to cover each
+// other's prologue / epilogue; below that (BASELINE configs[3] / [4] at 32 images per GPU: 64 / 256 tiles on 256
+// CUs) the gate-split plans run - 64- or 32-row tiles with one gate per wave, whichever still fills the chip.
+int g3_lstm_plan(const G3Batch& batch) {
+    int64_t t128 = 0, t64 = 0;
+    for (int i = 0; i < batch.count; ++i) {
+        t128 += cdiv(batch.p[i].m, 128) * cdiv(batch.p[i].n, 32);
+        t64 += cdiv(batch.p[i].m, 64) * cdiv(batch.p[i].n, 32);
+    }
+    // measured (two cells, n = 256, K = 880): R = 512: 35.0 / 22.9 / 18.6 us (128-row / 64-row / 32-row plan),
+    // R = 1024: 37.3 / 28.9 / 27.4, R = 2048: 45.3 / 47.0 / 56.1, R = 4096: 63-65 / 66-68 / 84
+    if (t128 >= tune_get("g3_lstm_small_tiles", 192)) return 2;
+    return t64 >= tune_get("g3_lstm_small_tiles64", 384) ? 4 : 3;
 }
 
 int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
@@ -820,11 +947,15 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
         max_n = p.n > max_n ? p.n : max_n;
     }
     if (!variant) variant = tune_get("g3_lstm_variant", 0);
-    if (!variant) variant = 2;
+    if (!variant) variant = g3_lstm_plan(batch);
     prof_before(0, st);
     int rc;
     if (variant == 1)
         rc = launch_g3_variant<256, 128, 8, 1, 4, true>(batch, max_m, max_n, st);
+    else if (variant == 3)
+        rc = launch_g3_variant<32, 128, 1, 4, 4, true>(batch, max_m, max_n, st);
+    else if (variant == 4)
+        rc = launch_g3_variant<64, 128, 2, 4, 4, true>(batch, max_m, max_n, st);
     else
         rc = launch_g3_variant<128, 128, 4, 1, 3, true>(batch, max_m, max_n, st);
     prof_after(0, st);

@@ -233,7 +233,7 @@ def _image(lib, check, device, t, k):
                                    # the shapes of tools/g3_lab.py (a stale lab record showed wrong
                                    # results on exactly these, under forced variants, and no test covered them)
                                    (4096, 256, 1024), (65536, 384, 256), (4096, 1024, 624)])
-@pytest.mark.parametrize("variant", [1, 2, 3], ids=["256x128", "128x128", "128x64"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7, 11, 12], ids=["256x128", "128x128", "128x64", "64x64", "128x64w8", "64x64s3"])
 @pytest.mark.parametrize("acc", [0, 1])
 def test_gemm_nt_images(device, m, n, k, variant, acc):
     lib, check = _lib()
@@ -271,14 +271,14 @@ def test_gemm_nt_images_six_products_kat(device):
     a, b, want = _kat_operands(m, n, k)
     a3 = _image(lib, check, device, a.to(device), k)
     b3 = _image(lib, check, device, b.to(device), k)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 7, 11, 12):
         cd = th.zeros(m, n, device=device)
         check(lib.marl_gemm_nt_images(a3.data_ptr(), b3.data_ptr(), None, cd.data_ptr(), n, m, n, k, 0, variant, None))
         assert th.equal(cd.cpu().double(), want)
 
 
 @pytest.mark.parametrize("m,n,nin", [(4096, 256, 368), (777, 23, 45), (96, 64, 96), (300, 80, 200), (512, 256, 624)])
-@pytest.mark.parametrize("variant", [1, 2], ids=["256rows", "128rows"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["256rows", "128rows", "32rows_gate_split", "64rows_gate_split"])
 def test_lstm_images(device, m, n, nin, variant):
     """fused cell (networks/recurrent.py:19-35) from images against float64, and the image of h' it writes
     against the image of the h' it wrote in fp32"""
@@ -307,6 +307,33 @@ def test_lstm_images(device, m, n, nin, variant):
     assert th.equal(hn[:, n:].cpu(), th.zeros(m, _p4(n) - n)) and th.equal(gt[:, 4 * n:].cpu(), th.zeros(m, _p4(4 * n) - 4 * n))
     nb = lib.marl_image_bytes(m, n)
     assert th.equal(_image(lib, check, device, hn, n)[:nb], h3n[:nb])
+
+
+@pytest.mark.parametrize("m,n,nin", [(512, 256, 624), (2048, 256, 624), (333, 100, 77)])
+def test_lstm_gate_split_equals_the_one_wave_form(device, m, n, nin):
+    """the small-batch plans (one gate per wave, 32- / 64-row tiles: BASELINE configs[3], [4] at 32 images per GPU)
+    run the same K loop and the same cell arithmetic as the 128-row kernel: h', c', the activated gates and the
+    image of h' are BIT-identical"""
+    lib, check = _lib()
+    g = th.Generator().manual_seed(3 * m + n + nin)
+    u, h, cprev = th.randn(m, nin, generator=g), th.randn(m, n, generator=g), th.randn(m, n, generator=g)
+    wih, whh = th.randn(4 * n, nin, generator=g) / nin ** 0.5, th.randn(4 * n, n, generator=g) / n ** 0.5
+    bias = th.randn(4 * n, generator=g)
+    img = lambda t, k: _image(lib, check, device, _padded(t.to(device), _p4(k)), k)  # noqa: E731
+    u3, h3, wih3, whh3 = img(u, nin), img(h, n), img(wih, nin), img(whh, n)
+    cpd, bd = _padded(cprev.to(device), _p4(n)), bias.to(device)
+    res = {}
+    for variant in (2, 3, 4):
+        hn, cn = th.zeros(m, _p4(n), device=device), th.zeros(m, _p4(n), device=device)
+        gt = th.zeros(m, _p4(4 * n), device=device)
+        h3n = th.zeros(lib.marl_image_bytes(m, n) + 256, dtype=th.uint8, device=device)
+        check(lib.marl_lstm_images(u3.data_ptr(), nin, h3.data_ptr(), wih3.data_ptr(), whh3.data_ptr(), bd.data_ptr(),
+                                   cpd.data_ptr(), hn.data_ptr(), cn.data_ptr(), gt.data_ptr(), h3n.data_ptr(), m, n,
+                                   _p4(n), _p4(4 * n), variant, 1, None))
+        res[variant] = (hn, cn, gt, h3n[: lib.marl_image_bytes(m, n)])
+    for variant in (3, 4):
+        for a, b, name in zip(res[2], res[variant], ("h", "c", "gates", "image")):
+            assert th.equal(a, b), (variant, name)
 
 
 @pytest.mark.parametrize("rows,ni,nj", [(4096, 1024, 368), (2048, 96, 80), (4096, 45, 384), (65536, 384, 256),
