@@ -71,7 +71,8 @@ EXPORTS = (
     "marl_cnn_wgrad marl_cnn_wgrad_scratch marl_tune marl_tune_get marl_draw_episode "
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
     "marl_graph_destroy marl_image_bytes marl_image_build marl_gemm_nt_images marl_gemm_nt_images_batch "
-    "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch marl_plan_query"
+    "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch marl_plan_query "
+    "marl_gemm_tn_images_cell marl_gemm_tn_images_cell_scratch"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -134,6 +135,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_profile_begin.argtypes = [_i, _i]
     lib.marl_profile_end.argtypes = [C.POINTER(C.c_double), C.POINTER(_i)]
     lib.marl_debug_buffer.argtypes = [_cfgp, _i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]
+    lib.marl_gemm_tn_images_cell_scratch.restype = _sz
+    lib.marl_gemm_tn_images_cell_scratch.argtypes = [_i, _i, _i, _i64]
+    lib.marl_gemm_tn_images_cell.argtypes = [_vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]
     lib.marl_plan_query.argtypes = [_cfgp, _i, C.c_char_p, C.POINTER(_i)]
     for name in EXPORTS:
         fn = getattr(lib, name)

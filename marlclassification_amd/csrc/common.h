@@ -230,12 +230,32 @@ struct G3TnArgs {
     int64_t rows, rows_per_split;
     float* csum;           // nullable: [splits][ni] column sums of A
     int gx, gy, gz, safe;  // filled by the launcher
+    int j_first;           // first column of B (and of the output) this launch covers (column tile by starts there)
+#ifdef MARL_G3_ABLATE
+    int abl;
+#endif
 };
 struct G3TnPlan {
     int variant, splits;
     int64_t rows_per_split;
 };
 G3TnPlan g3_tn_plan(int ni, int nj, int64_t rows);
+// Both weight gradients of ONE LSTM cell - dW_ih = G^T U and dW_hh = G^T H, the same gate-gradient image G as
+// A - as one launch (gemm_tn3_cell_kernel): the column tiles of U and of H that belong to the same (256-column
+// tile of G, row slab) are adjacent workgroups on one XCD, run in step and share G's slab through that XCD's L2,
+// so G (403 MB at C3) leaves HBM once instead of once per column tile.  `ih` / `hh` are complete descriptions of
+// the two products (out = their slabs, csum on `hh` or `ih`); the plan fixes one split count for both.
+constexpr int kMaxTnCell = 4;
+struct G3TnCell {
+    G3TnArgs t[kMaxTnCell];  // one entry per column tile: 256-wide ones first, then (at most one) 128-wide
+    int nt, n256;            // tiles in all, 256-wide ones
+    int gx, gz;
+    int halves_last;         // dispatch order (see the kernel)
+};
+bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows);
+G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows);
+size_t g3_tn_cell_scratch_bytes(int ni, int nj_ih, int nj_hh, int64_t rows);
+int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStream_t st);
 size_t g3_tn_scratch_bytes(int ni, int nj, int64_t rows);
 int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st);
 

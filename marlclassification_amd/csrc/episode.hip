@@ -498,6 +498,13 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
                 const size_t v = g3_tn_scratch_bytes(q[0], q[1], nr);
                 tns = v > tns ? v : tns;
             }
+            // (both products of a cell in one launch: their slabs side by side)
+            const int cell[2][3] = {{4 * d.n_b, d.nin, d.n_b}, {4 * d.n_a, d.nin, d.n_a}};
+            for (const auto& q : cell)
+                if (g3_tn_cell_ok(q[0], q[1], q[2], nr)) {
+                    const size_t v = g3_tn_cell_scratch_bytes(q[0], q[1], q[2], nr);
+                    tns = v > tns ? v : tns;
+                }
         }
         upd_tn(d.n_d, 2, nr);
         for (int l = 0; l < d.L; ++l) {
@@ -1245,6 +1252,37 @@ static int tn3(const Ctx& c, const char* a3, int ni, const char* b3, int nj, int
     MARL_TRY(launch_gemm_tn3(a, plan, c.st));
     return launch_slab_reduce(scratch, (int64_t)ni * nj, plan.splits, c.gp(pidx), c.w.ldp[pidx], ni, nj, a.csum, bias, c.st);
 }
+// both weight gradients of one LSTM cell from one launch (gemm3.hip, gemm_tn3_cell_kernel): G read once
+static int tn3_cell(const Ctx& c, const char* g3, int ni, const char* u3, int nin, int p_ih, const char* h3, int nh,
+                    int p_hh, int64_t rows, float* bias) {
+    const G3TnPlan plan = g3_tn_cell_plan(ni, nin, nh, rows);
+    if (g3_tn_cell_scratch_bytes(ni, nin, nh, rows) > c.e.tns_bytes) {
+        set_error("tn3_cell: scratch too small");
+        return MARL_ESIZE;
+    }
+    float* s_ih = c.at(c.e.TNS);
+    float* s_hh = s_ih + (size_t)plan.splits * ni * nin;
+    float* s_cs = s_hh + (size_t)plan.splits * ni * nh;
+    G3TnArgs ih{}, hh{};
+    ih.a3 = hh.a3 = g3;
+    ih.a_steps = hh.a_steps = img_steps(ni);
+    ih.ni = hh.ni = ni;
+    ih.rows = hh.rows = rows;
+    ih.b3 = u3;
+    ih.b_steps = img_steps(nin);
+    ih.nj = ih.ldo = nin;
+    ih.out = s_ih;
+    ih.out_split_stride = (int64_t)ni * nin;
+    ih.csum = bias ? s_cs : nullptr;  // (the column sums of G ride on the first tile of the launch)
+    hh.b3 = h3;
+    hh.b_steps = img_steps(nh);
+    hh.nj = hh.ldo = nh;
+    hh.out = s_hh;
+    hh.out_split_stride = (int64_t)ni * nh;
+    MARL_TRY(launch_gemm_tn3_cell(ih, hh, plan, c.st));
+    MARL_TRY(launch_slab_reduce(s_ih, (int64_t)ni * nin, plan.splits, c.gp(p_ih), c.w.ldp[p_ih], ni, nin, nullptr, nullptr, c.st));
+    return launch_slab_reduce(s_hh, (int64_t)ni * nh, plan.splits, c.gp(p_hh), c.w.ldp[p_hh], ni, nh, ih.csum, bias, c.st);
+}
 // scratch for `blocks` affine partial rows of width 2n: the queue's when the reduction can wait
 static float* part_scratch(const Ctx& c, int64_t blocks, int n, int acc, RedQueue*& q) {
     q = acc ? nullptr : c.rq;
@@ -1632,10 +1670,20 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     if (g3 && g3_tn_enabled(d)) {
         // contraction over the rows of the images written by the cell-backward kernels (gate gradients),
         // the forward kernels (U) and the LSTM epilogues (h, h^); bias gradients = column sums of A
-        MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.U3), d.nin, MARL_P_LB_WIH, NR, nullptr));
-        MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.H3), d.n_b, MARL_P_LB_WHH, NR, grads[MARL_P_LB_BIH]));
-        MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.U3), d.nin, MARL_P_LA_WIH, NR, nullptr));
-        MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.HC3), d.n_a, MARL_P_LA_WHH, NR, grads[MARL_P_LA_BIH]));
+        if (g3_tn_cell_ok(4 * d.n_b, d.nin, d.n_b, NR)) {
+            MARL_TRY(tn3_cell(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.U3), d.nin, MARL_P_LB_WIH, c.img(c.e.H3), d.n_b,
+                              MARL_P_LB_WHH, NR, grads[MARL_P_LB_BIH]));
+        } else {
+            MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.U3), d.nin, MARL_P_LB_WIH, NR, nullptr));
+            MARL_TRY(tn3(c, c.img(c.e.GB3), 4 * d.n_b, c.img(c.e.H3), d.n_b, MARL_P_LB_WHH, NR, grads[MARL_P_LB_BIH]));
+        }
+        if (g3_tn_cell_ok(4 * d.n_a, d.nin, d.n_a, NR)) {
+            MARL_TRY(tn3_cell(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.U3), d.nin, MARL_P_LA_WIH, c.img(c.e.HC3), d.n_a,
+                              MARL_P_LA_WHH, NR, grads[MARL_P_LA_BIH]));
+        } else {
+            MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.U3), d.nin, MARL_P_LA_WIH, NR, nullptr));
+            MARL_TRY(tn3(c, c.img(c.e.GA3), 4 * d.n_a, c.img(c.e.HC3), d.n_a, MARL_P_LA_WHH, NR, grads[MARL_P_LA_BIH]));
+        }
     } else {
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.at(c.e.U, 0), d.ld_nin, MARL_P_LB_WIH, 4 * d.n_b, d.nin, NR));
     MARL_TRY(tn(c, c.at(c.e.GB, 0), d.ld_gb, c.Hs(0), d.ld_nb, MARL_P_LB_WHH, 4 * d.n_b, d.n_b, NR, grads[MARL_P_LB_BIH]));

@@ -486,7 +486,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 // DB: fragments double-buffered in registers (step s + 1 read while step s multiplies, NST - 2 steps in
 // flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
 // fragments of step s are read right behind the barrier, NST - 1 steps in flight.
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
 __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsigned bx, int j0, unsigned bz, bool first_col_tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WI * WJ;
@@ -642,12 +642,20 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
         for (int g = 0; g < NST - 1; ++g)
             if (g < S) issue();
         int rslot = 0;
+        // ABL (perf diagnosis, tools/tn_ablate.py; wrong results): 1 no LDS-DMA in the loop, 2 no MFMA, 3 no
+        // fragment reads, 4 neither DMA nor fragment reads
+        if (ABL == 3 || ABL == 4) G3T_LOADF(fa0, fb0, 0)
         for (int s = 0; s < S; ++s) {
             if (!P.safe && gi < S) { G3T_WAIT(NST - 2) } else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
-            if (gi < S) issue();
-            G3T_LOADF(fa0, fb0, rslot)
-            G3T_MMA(fa0, fb0)
+            if (ABL == 1 || ABL == 4) { if (gi < S) ++gi; } else if (gi < S) issue();
+            if (ABL != 3 && ABL != 4) G3T_LOADF(fa0, fb0, rslot)
+            if (ABL != 2) { G3T_MMA(fa0, fb0) } else {
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[p][i]));
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb0[p][j]));
+                }
+            }
             rslot = rslot + 1 == NST ? 0 : rslot + 1;
         }
     }
@@ -706,12 +714,12 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #endif
 }
 
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
 __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (P.gx > 0) xcd_tile(P.gx, P.gy, P.gz, bx, by, bz);
-    gemm_tn3_body<BI, BJ, WI, WJ, NST, DB>(P, sm, bx, (int)by * BJ, bz, by == 0);
+    gemm_tn3_body<BI, BJ, WI, WJ, NST, DB, ABL>(P, sm, bx, P.j_first + (int)by * BJ, bz, by == 0);
 }
 
 // "column passes": a workgroup owns a 256-column tile of A and a row slab and walks ALL columns of B in
@@ -729,6 +737,36 @@ __global__ __launch_bounds__(512, 2) void gemm_tn3_passes_kernel(const G3TnArgs 
         else
             gemm_tn3_body<256, 128, 4, 2, 3, false>(P, sm, bx, j0, bz, j0 == 0);
     }
+}
+
+// One LSTM cell's two weight gradients in one launch (common.h, G3TnCell): workgroup = (row slab, 256-column
+// tile of G, column tile k of [U | H]), k fastest in the XCD-contiguous order - the nt workgroups that read the
+// same slab of G are dispatched next to each other on one XCD and walk it together.
+__global__ __launch_bounds__(512, 2) void gemm_tn3_cell_kernel(const G3TnCell P) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    unsigned bx, by, bz;
+    if (P.halves_last) {
+        // per XCD: the 256-wide tiles of its slabs first (team order), its 128-wide tiles behind them - whole
+        // rounds of equal workgroups (gz % 8 == 0, nt == n256 + 1: checked by the launcher)
+        const unsigned L = blockIdx.x, xcd = L & 7, slot = L >> 3, ns = P.gz >> 3;
+        const unsigned full = ns * P.gx * P.n256;
+        unsigned q = slot < full ? slot : slot - full;
+        if (slot < full) {
+            by = q % P.n256;
+            q /= P.n256;
+        } else {
+            by = P.n256;
+        }
+        bx = q % P.gx;
+        bz = xcd * ns + q / P.gx;
+    } else {
+        xcd_tile(P.gx, P.nt, P.gz, bx, by, bz);
+    }
+    const G3TnArgs& Q = P.t[by];
+    if ((int)by < P.n256)
+        gemm_tn3_body<256, 256, 4, 2, 3, false>(Q, sm, bx, Q.j_first, bz, Q.csum != nullptr);
+    else
+        gemm_tn3_body<256, 128, 4, 2, 3, false>(Q, sm, bx, Q.j_first, bz, false);
 }
 
 // ---------------------------------------------------------------------------
@@ -962,11 +1000,11 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
     return rc;
 }
 
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
 static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NST * ((BI + BJ) / 16) * 16 * kImgRowBytes;
     static_assert(lds <= 160 * 1024 && (size_t)WI * WJ * 32 * 36 * 4 <= lds, "LDS ring / epilogue panels");
-    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST, DB>;
+    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST, DB, ABL>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1021,6 +1059,9 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     }
     a.rows_per_split = plan.rows_per_split;
     a.safe = tune_get("g3_safe", 0) != 0;
+#ifdef MARL_G3_ABLATE
+    a.abl = tune_get("g3_tn_abl", 0);
+#endif
     const int bi = plan.variant == 2 ? 128 : 256, bj = plan.variant == 3 ? 256 : 128;
     dim3 grid((unsigned)cdiv(a.ni, bi), (unsigned)(plan.variant == 4 ? 1 : cdiv(a.nj, bj)), (unsigned)plan.splits);
     a.gx = a.gy = a.gz = 0;
@@ -1044,10 +1085,108 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
         rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
     } else if (plan.variant == 1)
         rc = launch_tn3_variant<256, 128, 4, 2, 4, true>(a, grid, st);
+#ifdef MARL_G3_ABLATE
+    else if (plan.variant == 3 && a.abl == 1) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 1>(a, grid, st);
+    else if (plan.variant == 3 && a.abl == 2) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 2>(a, grid, st);
+    else if (plan.variant == 3 && a.abl == 3) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 3>(a, grid, st);
+    else if (plan.variant == 3 && a.abl == 4) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 4>(a, grid, st);
+#endif
     else if (plan.variant == 3)
         rc = launch_tn3_variant<256, 256, 4, 2, 3, false>(a, grid, st);
     else
         rc = launch_tn3_variant<128, 128, 2, 2, 3, true>(a, grid, st);
+    prof_after(2, st);
+    return rc;
+}
+
+// ---- one cell's dW_ih and dW_hh in one launch ---------------------------------------------------------
+bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows) {
+    if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < 32768 || (rows & 31)) return false;
+    // column tiles: whole 256-wide ones plus at most one remainder of <= 128 columns, per operand
+    auto tiles = [](int nj, int& n256, int& n128) {
+        n256 = nj / 256;
+        const int rem = nj - n256 * 256;
+        n128 = 0;
+        if (rem > 128) ++n256;
+        else if (rem > 0) n128 = 1;
+    };
+    int a256, a128, b256, b128;
+    tiles(nj_ih, a256, a128);
+    tiles(nj_hh, b256, b128);
+    return a128 + b128 <= 1 && a256 + b256 + a128 + b128 <= kMaxTnCell && a256 + b256 >= 1;
+}
+G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
+    G3TnPlan p;
+    p.variant = 5;
+    // work per (G tile, row slab) in 256 x 256 units; the split count gives every CU the same number of units
+    const int units2 = 2 * ((nj_ih + 127) / 256 + (nj_hh + 127) / 256) + ((nj_ih % 256 > 0 && nj_ih % 256 <= 128) ? 1 : 0) +
+                       ((nj_hh % 256 > 0 && nj_hh % 256 <= 128) ? 1 : 0);  // in half units
+    (void)units2;
+    int64_t s = tune_get("g3_tn_cell_splits", 64);
+    const int64_t max_s = cdiv(rows, 256);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const int64_t rps = cdiv(cdiv(rows, s), 32) * 32;
+    p.splits = (int)cdiv(rows, rps);
+    p.rows_per_split = rps;
+    return p;
+}
+size_t g3_tn_cell_scratch_bytes(int ni, int nj_ih, int nj_hh, int64_t rows) {
+    const G3TnPlan p = g3_tn_cell_plan(ni, nj_ih, nj_hh, rows);
+    return (size_t)p.splits * ((size_t)ni * nj_ih + (size_t)ni * nj_hh + 2 * (size_t)ni) * sizeof(float);
+}
+
+int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStream_t st) {
+    for (const G3TnArgs* q : {&ih, &hh}) {
+        const G3TnArgs& a = *q;
+        if (!a.a3 || !a.b3 || !a.out || a.ni <= 0 || a.nj <= 0 || a.rows <= 0 || (a.rows & 31) || (a.a_row0 & 31) ||
+            (a.b_row0 & 31) || a.a_steps < img_steps(a.ni) || a.b_steps < img_steps(a.nj) || a.ni != ih.ni ||
+            a.rows != ih.rows || a.a3 != ih.a3) {
+            set_error("gemm_tn3_cell: bad operand (ni=%d nj=%d rows=%lld)", a.ni, a.nj, (long long)a.rows);
+            return MARL_EINVAL;
+        }
+        if ((int64_t)(plan.rows_per_split >> 5) * a.a_steps * kImgChunkBytes >= (1ll << 31) ||
+            (int64_t)(plan.rows_per_split >> 5) * a.b_steps * kImgChunkBytes >= (1ll << 31)) {
+            set_error("gemm_tn3_cell: split too long for 32-bit offsets");
+            return MARL_ELIMIT;
+        }
+    }
+    if (!g3_tn_cell_ok(ih.ni, ih.nj, hh.nj, ih.rows)) {
+        set_error("gemm_tn3_cell: shape outside the plan (ni=%d nj=%d/%d)", ih.ni, ih.nj, hh.nj);
+        return MARL_EINVAL;
+    }
+    G3TnCell c{};
+    int n = 0;
+    G3TnArgs last128{};
+    bool have128 = false;
+    for (G3TnArgs* q : {&ih, &hh}) {
+        q->rows_per_split = plan.rows_per_split;
+        q->safe = tune_get("g3_safe", 0) != 0;
+        float* csum = q->csum;
+        for (int j0 = 0; j0 < q->nj; j0 += 256) {
+            G3TnArgs t = *q;
+            t.j_first = j0;
+            t.csum = j0 == 0 ? csum : nullptr;  // (column sums of G: once)
+            if (q->nj - j0 > 128) c.t[n++] = t;
+            else last128 = t, have128 = true;
+        }
+    }
+    c.n256 = n;
+    if (have128) c.t[n++] = last128;
+    c.nt = n;
+    c.gx = (int)cdiv(ih.ni, 256);
+    c.gz = plan.splits;
+    c.halves_last = tune_get("g3_tn_cell_order", 0) == 1 && have128 && (c.gz & 7) == 0;
+    constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;
+    static bool raised = false;
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_cell_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    prof_before(2, st);
+    hipLaunchKernelGGL(gemm_tn3_cell_kernel, dim3((unsigned)(c.gx * c.nt * c.gz)), dim3(512), lds, st, c);
+    const int rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
     prof_after(2, st);
     return rc;
 }
@@ -1162,6 +1301,51 @@ int marl_gemm_tn_images(const void* a3, const void* b3, float* c, int ldc, int n
     a.csum = colsum ? scratch + (size_t)plan.splits * ni * nj : nullptr;
     MARL_TRY(launch_gemm_tn3(a, plan, st));
     return launch_slab_reduce(scratch, (int64_t)ni * nj, plan.splits, c, ldc, ni, nj, a.csum, colsum, st);
+}
+
+// both weight gradients of one LSTM cell (C_ih [NI, NIH] = G^T U, C_hh [NI, NHH] = G^T H, colsum = column sums of
+// G) from one launch that reads G once (gemm_tn3_cell_kernel); 0 bytes = shape outside the plan
+size_t marl_gemm_tn_images_cell_scratch(int ni, int nih, int nhh, int64_t rows) {
+    if (ni < 1 || nih < 1 || nhh < 1 || rows < 32 || rows % 32 != 0 || !marl::g3_tn_cell_ok(ni, nih, nhh, rows)) return 0;
+    return marl::g3_tn_cell_scratch_bytes(ni, nih, nhh, rows);
+}
+int marl_gemm_tn_images_cell(const void* g3, int ni, const void* u3, int nih, const void* h3, int nhh, int64_t rows,
+                             float* c_ih, int ld_ih, float* c_hh, int ld_hh, float* colsum, float* scratch,
+                             size_t scratch_bytes, void* stream) {
+    using namespace marl;
+    if (ni < 1 || nih < 1 || nhh < 1 || rows < 32 || rows % 32 != 0 || !g3 || !u3 || !h3 || !c_ih || !c_hh ||
+        !g3_tn_cell_ok(ni, nih, nhh, rows)) {
+        set_error("gemm_tn_images_cell: shape outside the plan (ni=%d nih=%d nhh=%d rows=%lld)", ni, nih, nhh, (long long)rows);
+        return MARL_EINVAL;
+    }
+    if (!scratch || scratch_bytes < g3_tn_cell_scratch_bytes(ni, nih, nhh, rows)) {
+        set_error("gemm_tn_images_cell: scratch too small");
+        return MARL_ESIZE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const G3TnPlan plan = g3_tn_cell_plan(ni, nih, nhh, rows);
+    float* s_ih = scratch;
+    float* s_hh = s_ih + (size_t)plan.splits * ni * nih;
+    float* s_cs = s_hh + (size_t)plan.splits * ni * nhh;
+    G3TnArgs ih{}, hh{};
+    ih.a3 = hh.a3 = static_cast<const char*>(g3);
+    ih.a_steps = hh.a_steps = img_steps(ni);
+    ih.ni = hh.ni = ni;
+    ih.rows = hh.rows = rows;
+    ih.b3 = static_cast<const char*>(u3);
+    ih.b_steps = img_steps(nih);
+    ih.nj = ih.ldo = nih;
+    ih.out = s_ih;
+    ih.out_split_stride = (int64_t)ni * nih;
+    ih.csum = colsum ? s_cs : nullptr;
+    hh.b3 = static_cast<const char*>(h3);
+    hh.b_steps = img_steps(nhh);
+    hh.nj = hh.ldo = nhh;
+    hh.out = s_hh;
+    hh.out_split_stride = (int64_t)ni * nhh;
+    MARL_TRY(launch_gemm_tn3_cell(ih, hh, plan, st));
+    MARL_TRY(launch_slab_reduce(s_ih, (int64_t)ni * nih, plan.splits, c_ih, ld_ih, ni, nih, nullptr, nullptr, st));
+    return launch_slab_reduce(s_hh, (int64_t)ni * nhh, plan.splits, c_hh, ld_hh, ni, nhh, ih.csum, colsum, st);
 }
 
 }  // extern "C"

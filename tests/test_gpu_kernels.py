@@ -371,6 +371,46 @@ def test_gemm_tn_images(device, rows, ni, nj, variant):
     assert th.equal(cd[:, nj:].cpu(), th.zeros(ni, ldc - nj))
 
 
+@pytest.mark.parametrize("rows,ni,nih,nhh", [(32768, 256, 368, 256), (32768 + 96, 512, 624, 256), (32768, 256, 300, 200),
+                                              (65536, 1024, 368, 256)])
+def test_gemm_tn_images_cell(device, rows, ni, nih, nhh):
+    """both weight gradients of an LSTM cell from ONE launch (G's row slabs shared through the L2 of an XCD): against
+    float64 within the row-contraction bound, bit-equal to its fully-waited build, column sums = bias gradient,
+    nothing written outside [NI, NJ]"""
+    lib, check = _lib()
+    gen = th.Generator().manual_seed(rows + ni + nih + nhh)
+    g, u, h = th.randn(rows, ni, generator=gen), th.randn(rows, nih, generator=gen), th.randn(rows, nhh, generator=gen)
+    g3 = _image(lib, check, device, _padded(g.to(device), _p4(ni)), ni)
+    u3 = _image(lib, check, device, _padded(u.to(device), _p4(nih)), nih)
+    h3 = _image(lib, check, device, _padded(h.to(device), _p4(nhh)), nhh)
+    ld_ih, ld_hh = _p4(nih) + 4, _p4(nhh) + 8
+    sb = lib.marl_gemm_tn_images_cell_scratch(ni, nih, nhh, rows)
+    assert sb > 0
+
+    def run():
+        scratch = th.zeros(sb // 4 + 16, device=device)
+        c_ih, c_hh, cs = th.zeros(ni, ld_ih, device=device), th.zeros(ni, ld_hh, device=device), th.zeros(ni, device=device)
+        check(lib.marl_gemm_tn_images_cell(g3.data_ptr(), ni, u3.data_ptr(), nih, h3.data_ptr(), nhh, rows, c_ih.data_ptr(),
+                                           ld_ih, c_hh.data_ptr(), ld_hh, cs.data_ptr(), scratch.data_ptr(), sb, None))
+        return c_ih, c_hh, cs
+
+    try:
+        check(lib.marl_tune(b"g3_safe", 1))
+        safe = run()
+    finally:
+        check(lib.marl_tune(b"g3_safe", 0))
+    for _ in range(2):
+        got = run()
+        assert all(th.equal(a, b) for a, b in zip(got, safe)), "pipelined build differs from the fully-waited one"
+    c_ih, c_hh, cs = got
+    gd = g.double()
+    assert (c_ih[:, :nih].cpu().double() - gd.t() @ u.double()).abs().max().item() <= TN_BOUND * _dot_scale(g.t(), u.t())
+    assert (c_hh[:, :nhh].cpu().double() - gd.t() @ h.double()).abs().max().item() <= TN_BOUND * _dot_scale(g.t(), h.t())
+    assert (cs.cpu().double() - gd.sum(0)).abs().max().item() <= TN_BOUND * g.abs().double().sum(0).max().item() * 2.0 ** -24 * 4
+    assert th.equal(c_ih[:, nih:].cpu(), th.zeros(ni, ld_ih - nih)) and th.equal(c_hh[:, nhh:].cpu(), th.zeros(ni, ld_hh - nhh))
+    assert lib.marl_gemm_tn_images_cell_scratch(ni, nih, nhh, 8192) == 0  # (short contractions keep the per-product kernels)
+
+
 @pytest.mark.parametrize("m,n", [(95, 24), (4096, 384), (7, 1), (300, 1000)])
 def test_ln_silu_fwd(device, m, n):
     lib, check = _lib()
