@@ -2000,6 +2000,10 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
     return MARL_OK;
 }
 
+// prefetch depths the kernel is instantiated with: {dZ float4, input items} per thread
+static const int kWgPref[2][2][2] = {{{2, 2}, {4, 4}},    // deeper layers (float4 of Z_{l-1})
+                                     {{2, 4}, {4, 14}}};  // first layer (raw pixels)
+
 // ---------------------------------------------------------------------------
 // Convolution weight gradient from the activations (backward of networks/vision.py:33-35,
 // training/trainer.py:115).  PERSISTENT workgroups (a few per CU) walk chunks of `rb` patches:
@@ -2325,9 +2329,324 @@ __global__ __launch_bounds__(512) void cnn_wgrad_kernel(const CnnWgradArgs A) {
     }
 }
 
-// prefetch depths the kernel is instantiated with: {dZ float4, input items} per thread
-static const int kWgPref[2][2][2] = {{{2, 2}, {4, 4}},    // deeper layers (float4 of Z_{l-1})
-                                     {{2, 4}, {4, 14}}};  // first layer (raw pixels)
+// ---------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe ("bf16x6") for the layers whose input has
+// >= 16 channels (the 3x3 weight gradients are matrix-pipe-bound on the exact-fp32 MFMA).
+//   * the staged dZ chunk and the recomputed layer input are split into three bf16 terms WHILE they go to
+//     LDS (split_pair: x0 + x1 + x2 == x), three planes each: Dz3[plane][m][co], In3[plane][patch][y][x][ci]
+//     (channels last, zero border);
+//   * dW[co][k] += sum_m dZ[m][co] * im2col[m][k] has the contraction index m as the ROW index of both
+//     operands, so the fragments of v_mfma_f32_32x32x16_bf16 (8 consecutive m per lane) come out of LDS
+//     with the transposing read ds_read_b64_tr_b16 exactly as in gemm_tn3_kernel - here with one address per
+//     lane: the implicit im2col is the per-lane gather (window origin of row m from the row table + the
+//     tap / channel offset of the lane's 4 columns; 4 consecutive ci never straddle a tap: cin % 16 == 0);
+//   * six products per fp32 product, smallest terms first, fp32 accumulation - the arithmetic of every other
+//     bf16x6 kernel; tiles are 32 (co) x 32 (k) x 16 (m), a wave owns one co tile and NKT k tiles;
+//   * row strides (cs2, zs2) are chosen so that the four rows of a 16-lane group and the two column halves
+//     of a 32-lane group fall on disjoint banks.
+// Same persistent-workgroup / partial-slab / fixed-order-reduction structure as cnn_wgrad_kernel.
+// ---------------------------------------------------------------------------
+typedef short wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) wg_s16x4* wg_tr_ptr;
+
+template <int NKT, int PD, int PI>
+__global__ __launch_bounds__(512) void cnn_wgrad3_kernel(const CnnWgradArgs A) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cin = A.cin, cout = A.cout, P = A.P, K = A.K, hp = A.hp, cs = A.cs, zs = A.zs;
+    const int rb = A.rb, in_per = A.in_per;  // (elements)
+    const int Mfull = rb * P, Mpad = (Mfull + 15) & ~15;
+    char* In3 = smem;                         // [3][rb][hp][hp][cs] bf16
+    char* Dz3 = smem + A.off_dz;              // [3][Mpad][zs] bf16   (off_dz, off_tab: bytes)
+    int* tab = reinterpret_cast<int*>(smem + A.off_tab);  // [Mpad] BYTE offset of row m's window in a plane
+    const int in_plane = A.in_plane, dz_plane = Mpad * zs * 2;  // bytes
+    const int ms = A.ms;
+    const int ms_id = wave % ms, tg = wave / ms;
+    const int ktg = tg % A.tgk, ct = tg / A.tgk;  // (tgc == nct: one 32-wide co tile per group)
+    const int kt0 = blockIdx.y * A.nkt_slab + ktg * NKT;
+    const int kt_end = min((int)(blockIdx.y + 1) * A.nkt_slab, A.nkt);
+
+    // fragment geometry (gemm_tn3_kernel): 16-lane group g16 -> column half sub, row half kg; lanes 4q .. 4q+3
+    // supply row q of a [4 rows][16 columns] block, 4 columns each
+    const int g16 = lane >> 4, sub = g16 & 1, kg = g16 >> 1, qrow = (lane >> 2) & 3, piece = lane & 3;
+    const int mrow = 8 * kg + qrow;            // row of read h = 0 inside a 16-row step (h = 1: + 4)
+    const int ccol = 16 * sub + 4 * piece;     // first of the lane's 4 columns inside a 32-wide tile
+    int toff[NKT];                             // BYTE offset of the lane's columns inside a row's window
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+        int kc = (kt0 + j) * 32 + ccol;
+        kc = kc < K ? kc : K - 4;              // (columns past K: computed on valid data, never stored)
+        const int tap = fdiv(kc, A.dcin), ci = kc - tap * cin;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        toff[j] = ((kh * hp + kw) * cs + ci) * 2;
+    }
+    const int aoff = (ct * 32 + ccol) * 2;
+    wg_f32x16 acc[NKT];
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- one-time LDS set-up: zeros (borders, padding rows), row table
+    for (int i = tid; i < A.lds_floats; i += 512) reinterpret_cast<float*>(smem)[i] = 0.f;
+    __syncthreads();
+    for (int m = tid; m < Mpad; m += 512) {
+        const int mm = m < Mfull ? m : 0;
+        const int lr = fdiv(mm, A.dP), opos = mm - lr * P;
+        const int oy = fdiv(opos, A.dhout), ox = opos - oy * A.hout;
+        tab[m] = (lr * in_per + (2 * oy * hp + 2 * ox) * cs) * 2;
+    }
+
+    // ---- staging roles (as cnn_wgrad_kernel: a thread keeps its four channels)
+    const int c4o = cout >> 2;
+    const int dz_c = (tid % c4o) * 4, dz_m0 = tid / c4o, dz_mstep = 512 / c4o;
+    const int Pin = A.hin * A.hin;
+    const int c4i = cin >> 2;
+    const int zi_c = (tid % c4i) * 4, zi_p0 = tid / c4i, zi_pstep = 512 / c4i;
+    const float4 gm4 = *reinterpret_cast<const float4*>(A.gamma + zi_c);
+    const float4 bt4 = *reinterpret_cast<const float4*>(A.beta + zi_c);
+    const int zi_g = zi_c / (cin / A.G);
+    int it_lr[PI], it_lo[PI], it_go[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int pl = zi_p0 + i * zi_pstep;  // patch-major input position
+        it_lr[i] = -1;
+        it_lo[i] = it_go[i] = 0;
+        if (pl < rb * Pin) {
+            const int lr = fdiv(pl, A.dPin), ipos = pl - lr * Pin;
+            const int iy = fdiv(ipos, A.dhin), ix = ipos - iy * A.hin;
+            it_lr[i] = lr;
+            it_lo[i] = (lr * in_per + ((iy + 1) * hp + ix + 1) * cs + zi_c) * 2;
+            it_go[i] = pl * cin + zi_c;
+        }
+    }
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pd[PD], pz[PI];
+    float2 ps[PI];
+
+    auto prefetch = [&](int chunk) {
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+        const int M = nrow * P;
+        const float* dsrc = A.dz + row0 * P * (int64_t)cout + dz_c;
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            const int m = dz_m0 + i * dz_mstep;
+            pd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) pd[i] = *reinterpret_cast<const float4*>(dsrc + (int64_t)m * cout);
+        }
+        const float* zsrc = A.zin + row0 * Pin * (int64_t)cin;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            pz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ps[i] = make_float2(0.f, 0.f);
+            if ((unsigned)it_lr[i] < (unsigned)nrow) {
+                pz[i] = *reinterpret_cast<const float4*>(zsrc + it_go[i]);
+                ps[i] = *reinterpret_cast<const float2*>(A.gst + ((row0 + it_lr[i]) * A.G + zi_g) * 2);
+            }
+        }
+    };
+    // four consecutive values -> 8 bytes in each of the three planes
+    auto put3 = [&](char* base, int plane_bytes, float a, float b, float c, float d) {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        split_pair(a, b, a0, a1, a2);
+        split_pair(c, d, b0, b1, b2);
+        *reinterpret_cast<uint2*>(base) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(base + plane_bytes) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(base + 2 * plane_bytes) = make_uint2(a2, b2);
+    };
+    auto stage = [&](int chunk) {
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            const int m = dz_m0 + i * dz_mstep;
+            if (m < Mpad) {  // rows past this chunk's M hold zeros (they multiply stale inputs)
+                put3(Dz3 + (m * zs + dz_c) * 2, dz_plane, pd[i].x, pd[i].y, pd[i].z, pd[i].w);
+                bsum.x += pd[i].x;
+                bsum.y += pd[i].y;
+                bsum.z += pd[i].z;
+                bsum.w += pd[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            if ((unsigned)it_lr[i] < (unsigned)nrow) {
+                const float mean = ps[i].x, rstd = ps[i].y;
+                put3(In3 + it_lo[i], in_plane, cnn_silu((pz[i].x - mean) * rstd * gm4.x + bt4.x),
+                     cnn_silu((pz[i].y - mean) * rstd * gm4.y + bt4.y), cnn_silu((pz[i].z - mean) * rstd * gm4.z + bt4.z),
+                     cnn_silu((pz[i].w - mean) * rstd * gm4.w + bt4.w));
+            }
+        }
+    };
+#define WG3_FRAG(p0_, p1_)                                                                         \
+    __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_tr_ptr)(p0_)),             \
+                            __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_tr_ptr)(p1_)), 0, 1, 2, 3, 4, 5, 6, 7)
+
+    int chunk = blockIdx.x;
+    if (chunk < A.nchunks) prefetch(chunk);
+    for (; chunk < A.nchunks; chunk += gridDim.x) {
+        __syncthreads();  // every wave is done with the previous chunk's LDS image
+        stage(chunk);
+        __syncthreads();
+        if (chunk + (int)gridDim.x < A.nchunks) prefetch(chunk + gridDim.x);
+        const int64_t row0 = (int64_t)chunk * rb;
+        const int nrow = (int)(A.rows - row0 < rb ? A.rows - row0 : rb);
+        const int msteps = (nrow * P + 15) >> 4;
+        for (int s = ms_id; s < msteps; s += ms) {
+            const int m0 = s * 16 + mrow;
+            const int w0 = tab[m0], w1 = tab[m0 + 4];
+            const char* da = Dz3 + (m0 * zs) * 2 + aoff;
+            wg_bf16x8 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[p] = WG3_FRAG(da + p * dz_plane, da + p * dz_plane + 4 * zs * 2);
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                wg_bf16x8 fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[p] = WG3_FRAG(In3 + p * in_plane + w0 + toff[j], In3 + p * in_plane + w1 + toff[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#undef WG3_FRAG
+
+    // ---- waves that shared tiles (different row-step phases) are summed through LDS in a fixed order, one k
+    // tile at a time (a 32 x 32 tile of every wave = 32 KB), then the partial slab goes to global:
+    // acc[j][r] = dW[co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][k = kt * 32 + (lane & 31)]
+    float* red = reinterpret_cast<float*>(smem);  // [8 waves][64 lanes][16]
+    float* pw = A.part_w + (size_t)blockIdx.x * cout * K;  // grid.y slabs are disjoint in k
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+        wg_f32x16 v = acc[j];
+        if (ms > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<cf32x4*>(red + (wave * 64 + lane) * 16 + 4 * q) =
+                    cf32x4{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+            __syncthreads();
+            if (ms_id == 0)
+                for (int q = 1; q < ms; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += red[((wave + q) * 64 + lane) * 16 + r];
+        }
+        const int kt = kt0 + j, kcol = kt * 32 + (lane & 31);
+        if (ms_id == 0 && kt < kt_end && kcol < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < cout) pw[(size_t)co * K + kcol] = v[r];
+            }
+        }
+    }
+    // bias gradient: column sums of dZ, taken from the staged values
+    if (A.part_b && blockIdx.y == 0) {
+        __syncthreads();
+        float4* sh4 = reinterpret_cast<float4*>(smem);
+        sh4[tid] = bsum;
+        __syncthreads();
+        if (tid < c4o) {
+            float4 t = sh4[tid];
+            for (int q = 1; q < dz_mstep; ++q) {
+                const float4 u = sh4[q * c4o + tid];
+                t.x += u.x;
+                t.y += u.y;
+                t.z += u.z;
+                t.w += u.w;
+            }
+            *reinterpret_cast<float4*>(A.part_b + (size_t)blockIdx.x * cout + tid * 4) = t;
+        }
+    }
+#endif
+}
+
+// wave roles / chunk size of the bf16x6 form; returns the dynamic LDS BYTES (0 = this form does not apply)
+static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
+    if (a.first || !split_mode() || tune_get("wgrad3", 1) == 0) return 0;
+    if ((a.cin & 15) || (a.cout & 31) || a.cout > 256 || 512 % (a.cout / 4) != 0 || 512 % (a.cin / 4) != 0 ||
+        a.cin % a.G != 0 || ((a.cin / a.G) & 3) || a.hin > 64 || a.rows <= 0)
+        return 0;
+    const int nct = a.cout / 32;
+    if (nct != 1 && nct != 2 && nct != 4 && nct != 8) return 0;
+    a.nct = nct;
+    a.nkt = (a.K + 31) / 32;
+    // waves: tgc = nct co tiles x tgk k-tile groups x ms row-step phases; NKT k tiles per wave (5, or 9 when a
+    // workgroup would otherwise need a second slab = a second staging pass over every patch)
+    int best_nkt = 0, best_tgk = 0, best_slabs = 1 << 30;
+    for (int nktw : {5, 9}) {
+        const int tgk_max = 8 / nct;
+        int tgk = 1;
+        while (tgk < tgk_max && tgk * nktw < a.nkt) tgk <<= 1;
+        const int slabs = (int)cdiv(a.nkt, tgk * nktw);
+        if (slabs < best_slabs) best_slabs = slabs, best_nkt = nktw, best_tgk = tgk;
+    }
+    if (best_slabs > 2) return 0;
+    a.slabs = best_slabs;
+    a.nkt_slab = (int)cdiv(a.nkt, a.slabs);
+    a.slabs = (int)cdiv(a.nkt, a.nkt_slab);
+    a.tgc = nct;
+    a.tgk = best_tgk;
+    a.ms = 8 / (nct * best_tgk);
+    a.sct = 1;
+    a.skt = best_nkt;
+    a.hp = a.hin + 2;
+    // row strides in bf16 elements: consecutive m (two pixels / one dZ row apart) 64 bytes apart modulo the 256-byte
+    // bank row, so the four rows of a 16-lane group and the two column halves (+32 bytes) never share a bank
+    a.cs = a.cin;
+    while ((4 * a.cs) % 256 != 64 && (4 * a.cs) % 256 != 192) a.cs += 8;
+    a.zs = a.cout;
+    while ((2 * a.zs) % 256 != 64 && (2 * a.zs) % 256 != 192) a.zs += 8;
+    a.in_per = a.hp * a.hp * a.cs;
+    a.dP = make_fdiv(a.P);
+    a.dhout = make_fdiv(a.hout);
+    a.dPin = make_fdiv(a.hin * a.hin);
+    a.dhin = make_fdiv(a.hin);
+    a.dcin = make_fdiv(a.cin);
+    const int lds_cap_kb = tune_get("wgrad3_lds_kb", best_nkt == 9 ? 150 : 76);
+    int rb_cap = tune_get("wgrad3_rb", 16);
+    if (rb_cap < 1) rb_cap = 1;
+    for (int v = 0; v < 2; ++v) {
+        const int PD = kWgPref[0][v][0], PI = kWgPref[0][v][1];
+        for (int rb = rb_cap; rb >= 1; --rb) {
+            const int M = rb * a.P, Mpad = (M + 15) & ~15;
+            if ((int64_t)Mpad * a.cout > (int64_t)PD * 512 * 4) continue;
+            if ((int64_t)rb * a.hin * a.hin * a.cin > (int64_t)PI * 512 * 4) continue;
+            const size_t in_plane = (((size_t)rb * a.in_per * 2) + 15) & ~(size_t)15;
+            const size_t off_dz = 3 * in_plane;
+            const size_t off_tab = off_dz + 3 * (size_t)Mpad * a.zs * 2;
+            size_t tot = off_tab + (size_t)Mpad * 4;
+            if (tot < 32768 + 0) tot = 32768;  // tile reduction / bias reduction scratch
+            tot = (tot + 15) & ~(size_t)15;
+            if (tot > (size_t)lds_cap_kb * 1024 && rb > 1) continue;
+            if (tot > 150 * 1024) break;
+            a.rb = rb;
+            a.pd = PD;
+            a.pi = PI;
+            a.in_plane = (int)in_plane;
+            a.off_dz = (int)off_dz;
+            a.off_tab = (int)off_tab;
+            a.lds_floats = (int)(tot / 4);
+            a.nchunks = (int)cdiv(a.rows, rb);
+            const int per_cu = best_nkt == 9 ? 1 : 2;
+            int blocks = 256 * per_cu / a.slabs;
+            if (blocks < 64) blocks = 64;
+            a.blocks = a.nchunks < blocks ? a.nchunks : blocks;
+            return tot;
+        }
+    }
+    return 0;
+}
 
 // picks the wave roles and the chunk size; returns the dynamic LDS floats (0 = unsupported)
 static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
@@ -2432,12 +2751,15 @@ int cnn_wgrad_supported(const CnnWgradArgs& a0) {
     if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
     if (getenv("MARL_CNN_WGRAD") && getenv("MARL_CNN_WGRAD")[0] == '0') return 0;
     CnnWgradArgs a = a0;
-    return cnn_wgrad_plan(a) > 0;
+    return cnn_wgrad_plan(a) > 0;  // (the bf16x6 form covers a subset of these shapes)
 }
 
 int cnn_wgrad_blocks(const CnnWgradArgs& a0) {
-    CnnWgradArgs a = a0;
-    return cnn_wgrad_plan(a) > 0 ? a.blocks : 0;
+    // (an upper bound for the scratch: the larger of the two forms' workgroup counts)
+    CnnWgradArgs a = a0, b = a0;
+    const int n1 = cnn_wgrad_plan(a) > 0 ? a.blocks : 0;
+    const int n3 = cnn_wgrad3_plan(b) > 0 ? b.blocks : 0;
+    return n1 > n3 ? n1 : n3;
 }
 
 template <int NCT, int NKT, bool FIRST, int PD, int PI>
@@ -2477,8 +2799,48 @@ static int wgrad_occupancy(size_t lds) {
     return occ;
 }
 
+template <int NKT, int PD, int PI>
+static int wgrad3_launch(CnnWgradArgs& a, float* part_w, size_t lds, hipStream_t st) {
+    auto kern = cnn_wgrad3_kernel<NKT, PD, PI>;
+    static bool raised = false;  // per process; one process drives one GPU (see marl_hip.h)
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        raised = true;
+    }
+    static size_t seen_lds[8];
+    static int seen_occ[8], nseen = 0;
+    int occ = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen_lds[i] == lds) occ = seen_occ[i];
+    if (!occ) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 512, lds) != hipSuccess ||
+            occ < 1)
+            occ = 1;
+        if (nseen < 8) seen_lds[nseen] = lds, seen_occ[nseen++] = occ;
+    }
+    int res = 256 * occ / a.slabs;
+    if (res < 64) res = 64;
+    if (res < a.blocks) a.blocks = res;
+    a.part_b = part_w + (size_t)a.blocks * a.cout * a.K;
+    prof_before(5, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.blocks, (unsigned)a.slabs), dim3(512), lds, st, a);
+    prof_after(5, st);
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
 int launch_cnn_wgrad(CnnWgradArgs& a, hipStream_t st) {
     float* part_w = a.part_w;
+    {   // layers with >= 16 input channels: the bf16x6 form
+        CnnWgradArgs b = a;
+        const size_t lds3 = cnn_wgrad3_plan(b);
+        if (lds3) {
+            a = b;
+            if (a.skt == 9) return a.pd == 4 ? wgrad3_launch<9, 4, 4>(a, part_w, lds3, st) : wgrad3_launch<9, 2, 2>(a, part_w, lds3, st);
+            return a.pd == 4 ? wgrad3_launch<5, 4, 4>(a, part_w, lds3, st) : wgrad3_launch<5, 2, 2>(a, part_w, lds3, st);
+        }
+    }
     const size_t fl = cnn_wgrad_plan(a);
     if (!fl) {
         set_error("conv weight gradient: shape outside the fused kernel's range");

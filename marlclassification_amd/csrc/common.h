@@ -843,6 +843,7 @@ struct CnnWgradArgs {
     int rb, nchunks, blocks;      // patches per chunk, chunks, persistent workgroups (grid.x)
     int hp, cs, zs, in_per;       // padded input side / channel stride / dZ row stride / floats per patch
     int off_dz, off_tab, lds_floats;
+    int in_plane;                 // (bf16x6 form) bytes of one plane of the staged input
     int nct, nkt, nkt_slab, slabs;  // 16-wide tiles of cout / K, k tiles per grid.y slab
     int tgc, tgk, ms;             // wave roles: cout-tile groups x k-tile groups x row-step interleave
     int sct, skt;                 // accumulator tiles per wave (template shape of the launch)

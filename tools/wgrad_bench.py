@@ -17,6 +17,10 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 variants = [v for v in (sys.argv[2].split(";") if len(sys.argv) > 2 else [""])]
 LAYERS = [  # cin, cout, hin, groups of the layer below, first
     (3, 16, 12, 1, True), (16, 32, 6, 2, False), (32, 64, 3, 4, False)]
+if os.environ.get("WGRAD_SET") == "aid32":  # BASELINE configs[4]: AidCnn on 32 x 32 patches (deeper layers only)
+    LAYERS = [(16, 32, 16, 2, False), (32, 64, 8, 4, False), (64, 128, 4, 8, False)]
+if os.environ.get("WGRAD_SET") == "aid24":  # configs[3]: f = 24
+    LAYERS = [(16, 32, 12, 2, False), (32, 64, 6, 4, False), (64, 128, 3, 8, False)]
 nb, H, W = 256, 256, 256
 g = th.Generator(device=dev).manual_seed(0)
 
