@@ -2584,6 +2584,8 @@ static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
     // waves: tgc = nct co tiles x tgk k-tile groups x ms row-step phases; NKT k tiles per wave (5, or 9 when a
     // workgroup would otherwise need a second slab = a second staging pass over every patch)
     int best_nkt = 0, best_tgk = 0, best_slabs = 1 << 30;
+    // (3 k tiles per wave at <= 128 registers - two workgroups per CU - spills 31 registers into the matrix loop:
+    // not instantiated)
     for (int nktw : {5, 9}) {
         const int tgk_max = 8 / nct;
         int tgk = 1;
@@ -2613,6 +2615,7 @@ static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
     a.dPin = make_fdiv(a.hin * a.hin);
     a.dhin = make_fdiv(a.hin);
     a.dcin = make_fdiv(a.cin);
+    if (best_nkt == 0) return 0;
     const int lds_cap_kb = tune_get("wgrad3_lds_kb", best_nkt == 9 ? 150 : 76);
     int rb_cap = tune_get("wgrad3_rb", 16);
     if (rb_cap < 1) rb_cap = 1;
