@@ -250,7 +250,7 @@ struct G3TnCell {
     G3TnArgs t[kMaxTnCell];  // one entry per column tile: 256-wide ones first, then (at most one) 128-wide
     int nt, n256;            // tiles in all, 256-wide ones
     int gx, gz;
-    int halves_last;         // dispatch order (see the kernel)
+    int halves_last, teams;  // dispatch order (see the kernel)
 };
 bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows);
 G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows);

@@ -486,7 +486,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 // DB: fragments double-buffered in registers (step s + 1 read while step s multiplies, NST - 2 steps in
 // flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
 // fragments of step s are read right behind the barrier, NST - 1 steps in flight.
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0, bool CS = true>
 __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsigned bx, int j0, unsigned bz, bool first_col_tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WI * WJ;
@@ -557,17 +557,17 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
     const char* lB0 = sm + A_BYTES + wn * (BJ / WJ / 16) * CS_BYTES + f0;
     const char* lB1 = sm + A_BYTES + wn * (BJ / WJ / 16) * CS_BYTES + f1;
 
-    f32x16 acc[TM][TN], accs[TM];
+    f32x16 acc[TM][TN], accs[CS ? TM : 1];  // (CS = false: no column sums of A - their accumulators are not even allocated)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accs[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accs[CS ? i : 0][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    const bool do_csum = P.csum != nullptr && first_col_tile;
+    const bool do_csum = CS && P.csum != nullptr && first_col_tile;
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;  // bf16 1.0
@@ -596,7 +596,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
     if (do_csum) {                                                                                   \
         _Pragma("unroll") for (int p = 2; p >= 0; --p)                                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
-                accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[p][i], ones, accs[i], 0, 0, 0); \
+                accs[CS ? i : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[p][i], ones, accs[CS ? i : 0], 0, 0, 0); \
     }
 #define G3T_WAIT(k_)                                                                                 \
     if (I_EXTRA > 0 && extra_i) wait_vm<(k_) * NI_HI>(); else wait_vm<(k_) * NI_LO>();
@@ -682,7 +682,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb + (r & 3) + 8 * (r >> 2) + row_h;
-                if (row < P.ni) co[row] = accs[i][r];
+                if (row < P.ni) co[row] = accs[CS ? i : 0][r];
             }
         }
 #pragma unroll
@@ -759,6 +759,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn3_cell_kernel(const G3TnCell P)
         }
         bx = q % P.gx;
         bz = xcd * ns + q / P.gx;
+    } else if (P.teams) {
+        // equal-work teams: per (row slab, PAIR of 256-column tiles of G): the 256-wide column tiles of both G tiles
+        // and ONE 512 (both G tiles) x 128 workgroup for the narrow last column tile - 2 n256 + 1 workgroups of the
+        // same length that walk the slab in step (a 256 x 128 tile would run twice as fast, away from its team)
+        const unsigned per = 2 * P.n256 + 1, T = (P.gx >> 1) * per * P.gz, L = blockIdx.x;
+        const unsigned chunk = T >> 3, rem = T & 7, xcd = L & 7, slot = L >> 3;
+        unsigned q = (xcd < rem ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk) + slot;
+        const unsigned m = q % per;
+        q /= per;
+        const unsigned pair = q % (P.gx >> 1);
+        bz = q / (P.gx >> 1);
+        if (m == 2 * (unsigned)P.n256) {
+            const G3TnArgs& Q = P.t[P.n256];
+            gemm_tn3_body<512, 128, 4, 2, 2, false, 0, false>(Q, sm, pair, Q.j_first, bz, false);
+            return;
+        }
+        bx = 2 * pair + m / P.n256;
+        by = m % P.n256;
     } else {
         xcd_tile(P.gx, P.nt, P.gz, bx, by, bz);
     }
@@ -1115,6 +1133,12 @@ bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows) {
     tiles(nj_hh, b256, b128);
     return a128 + b128 <= 1 && a256 + b256 + a128 + b128 <= kMaxTnCell && a256 + b256 >= 1;
 }
+// teams (see the kernel): a narrow last tile exists and G's 256-column tiles pair up
+static bool g3_tn_cell_teams(int ni, int nj_ih, int nj_hh) {
+    const int r1 = nj_ih % 256, r2 = nj_hh % 256;
+    const bool narrow = (r1 > 0 && r1 <= 128) || (r2 > 0 && r2 <= 128);
+    return tune_get("g3_tn_cell_teams", 1) != 0 && narrow && ni % 512 == 0;
+}
 G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
     G3TnPlan p;
     p.variant = 5;
@@ -1123,6 +1147,14 @@ G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
                        ((nj_hh % 256 > 0 && nj_hh % 256 <= 128) ? 1 : 0);  // in half units
     (void)units2;
     int64_t s = tune_get("g3_tn_cell_splits", 64);
+    if (g3_tn_cell_teams(ni, nj_ih, nj_hh) && tune_get("g3_tn_cell_splits", 0) == 0) {
+        // equal workgroups, (ni / 512) (2 n256 + 1) of them per slab: the split count that fills whole rounds of 256
+        const int n256 = ((nj_ih > 128 ? (nj_ih % 256 > 128 || nj_ih % 256 == 0 ? (nj_ih + 255) / 256 : nj_ih / 256) : 0) +
+                          (nj_hh > 128 ? (nj_hh % 256 > 128 || nj_hh % 256 == 0 ? (nj_hh + 255) / 256 : nj_hh / 256) : 0));
+        const int64_t units = (int64_t)(ni / 512) * (2 * n256 + 1);
+        const int64_t rounds = cdiv(units * 64, 256);
+        s = 256 * rounds / units;
+    }
     const int64_t max_s = cdiv(rows, 256);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -1177,6 +1209,8 @@ int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStre
     c.gx = (int)cdiv(ih.ni, 256);
     c.gz = plan.splits;
     c.halves_last = tune_get("g3_tn_cell_order", 0) == 1 && have128 && (c.gz & 7) == 0;
+    c.teams = !c.halves_last && have128 && g3_tn_cell_teams(ih.ni, ih.nj, hh.nj);
+    const unsigned total = c.teams ? (unsigned)((c.gx >> 1) * (2 * c.n256 + 1) * c.gz) : (unsigned)(c.gx * c.nt * c.gz);
     constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;
     static bool raised = false;
     if (!raised) {
@@ -1185,7 +1219,7 @@ int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStre
         raised = true;
     }
     prof_before(2, st);
-    hipLaunchKernelGGL(gemm_tn3_cell_kernel, dim3((unsigned)(c.gx * c.nt * c.gz)), dim3(512), lds, st, c);
+    hipLaunchKernelGGL(gemm_tn3_cell_kernel, dim3(total), dim3(512), lds, st, c);
     const int rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
     prof_after(2, st);
     return rc;

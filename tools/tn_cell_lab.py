@@ -21,9 +21,9 @@ for rows, ni, nih, nhh in ((65536, 1024, 368, 256), (65536, 1024, 624, 256)):
 
     us_old = timeit(old, 20)
     ref_ih, ref_hh = c_ih.clone(), c_hh.clone()
-    for splits, order in ((64, 0), (64, 1), (128, 0), (128, 1), (32, 1), (64, 0)):
+    for splits, order in ((64, 0), (0, 2), (64, 0), (0, 2), (60, 2), (90, 2)):
         check(lib.marl_tune(b"g3_tn_cell_splits", splits))
-        check(lib.marl_tune(b"g3_tn_cell_order", order))
+        check(lib.marl_tune(b"g3_tn_cell_teams", 1 if order == 2 else 0))
         sb = lib.marl_gemm_tn_images_cell_scratch(ni, nih, nhh, rows)
         sc = th.zeros(sb // 4 + 16, device=dev)
         new = lambda: check(lib.marl_gemm_tn_images_cell(g3.data_ptr(), ni, u3.data_ptr(), nih, h3.data_ptr(), nhh, rows, c_ih.data_ptr(), c_ih.shape[1], c_hh.data_ptr(), nhh, cs.data_ptr(), sc.data_ptr(), sb, None))
