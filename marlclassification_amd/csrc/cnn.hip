@@ -1509,7 +1509,12 @@ __device__ __forceinline__ float cnn_silu_grad(float y) {
     return silu_grad_fast(y);
 }
 
-__global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
+// W0 (the launch that produces dZ_0): the FIRST layer's weight gradient is formed right here from the dZ_0 panel in
+// LDS and the raw image patch (gathered at the saved positions into a zero-bordered LDS image), as in
+// cnn_wgrad_kernel<.., FIRST>: dZ_0 - the largest activation gradient of the network (1 GB at BASELINE configs[4]) -
+// is neither written nor read back, and the separate first-layer launch disappears.
+template <bool W0>
+__global__ __launch_bounds__(512, W0 ? 4 : 1) void cnn_dgrad_kernel(const CnnDgradArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Dz = lds;                    // [rb * P][cout + 4]
     float* Zin = lds + A.off_zin;       // [rb * Pin][cin + 4]
@@ -1551,7 +1556,42 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
             *reinterpret_cast<float4*>(Zin + m * cs + k) = *reinterpret_cast<const float4*>(zsrc + (int64_t)m * cin + k);
         }
         for (int idx = tid; idx < nrow * G * 2; idx += nthreads) gstat[idx] = A.gst[row0 * G * 2 + idx];
+        if constexpr (W0) {  // raw patches of the chunk -> interior of the zero-bordered images [lr][y + 1][x + 1][ci]
+            float* Pix = lds + A.off_pix;
+            const int f0 = A.f0, ff = f0 * f0, pe = A.cin0 * ff;
+            const int64_t plane = (int64_t)A.c_img * A.H * A.W;
+            const float* imgf = static_cast<const float*>(A.img);
+            const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
+            for (int idx = tid; idx < nrow * pe; idx += nthreads) {
+                const int lr = fdiv(idx, A.dpe0), e = idx - lr * pe;
+                const int ci = fdiv(e, A.dff0), e2 = e - ci * ff;
+                const int iy = fdiv(e2, A.df0), ix = e2 - iy * f0;
+                const int64_t r = row0 + lr;
+                const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
+                const int64_t off = (r % A.nb) * plane + (int64_t)(ci * A.H + p0 + iy) * A.W + p1 + ix;
+                Pix[lr * A.pix_per + ((iy + 1) * (f0 + 2) + ix + 1) * A.cs0 + ci] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
+            }
+        }
     };
+    // first-layer weight gradient (W0): per-lane window offsets of the lane's im2col columns, accumulators that
+    // live across all chunks of the workgroup (two 16-wide k tiles cover K0 = 9 * cin0 <= 32)
+    constexpr int NK0 = 2;
+    int toff0[NK0];
+    cf32x4 acc0[NK0];
+    float bsum0 = 0.f;
+    if constexpr (W0) {
+#pragma unroll
+        for (int j = 0; j < NK0; ++j) {
+            int kc = j * 16 + l16;
+            kc = kc < A.K0 ? kc : A.K0 - 1;
+            const int tap = kc / A.cin0, ci = kc - tap * A.cin0;
+            toff0[j] = ((tap / 3) * (A.f0 + 2) + (tap % 3)) * A.cs0 + ci;
+            acc0[j] = cf32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float* Pix = lds + A.off_pix;  // zero once: the borders are never written again
+        for (int i = tid; i < A.rb * A.pix_per; i += nthreads) Pix[i] = 0.f;
+        __syncthreads();
+    }
 
     // transposed convolution: wave w owns column tile nt = w % NT and a CONTIGUOUS range of row tiles
     // (same parity class -> same taps, so one weight fragment feeds all of them)
@@ -1797,10 +1837,30 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
         MARL_TS();
         __syncthreads();
         MARL_TS();
+        if constexpr (W0) {
+            // ---- dW_0[co][k] += sum_m dZ_0[m][co] * im2col(patch)[m][k] on 16x16x4 f32 MFMA tiles: A = the dZ_0 panel
+            // (rows m = patch-major layer-0 output positions), B gathered from the pixel image; wave w takes the row
+            // steps s = w, w + nwaves, ...
+            const float* Pix = lds + A.off_pix;
+            const int M0 = nrow * Pin, msteps = (M0 + 3) >> 2;
+            for (int s0 = wave; s0 < msteps; s0 += nwaves) {
+                const int m = s0 * 4 + quad;
+                const bool mv = m < M0;
+                const int mm = mv ? m : 0;
+                const int lr = fdiv(mm, A.dPin), ipos = mm - lr * Pin;
+                const int oy = fdiv(ipos, A.dhin0), ox = ipos - oy * hin;
+                const float a = (mv && l16 < cin) ? Da[mm * cs + l16] : 0.f;
+                const float* win = Pix + lr * A.pix_per + (2 * oy * (A.f0 + 2) + 2 * ox) * A.cs0;
+                bsum0 += a;
+#pragma unroll
+                for (int j = 0; j < NK0; ++j) acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, win[toff0[j]], acc0[j], 0, 0, 0);
+            }
+            __syncthreads();  // the pixel images are free: the next chunk's may land
+        }
         // ---- the next chunk's loads go out first (Dz, Zin and the statistics are free from here on),
         // then dZ_{l-1} of this chunk -> global (coalesced)
         if (chunk + (int)gridDim.x < nchunks) stage(chunk + (int)gridDim.x);
-        {
+        if (A.dzin) {
             const int Mi = nrow * Pin, i4 = cin >> 2;
             float* dst = A.dzin + row0 * Pin * (int64_t)cin;
             for (int idx = tid; idx < Mi * i4; idx += nthreads) {
@@ -1827,6 +1887,35 @@ __global__ __launch_bounds__(512) void cnn_dgrad_kernel(const CnnDgradArgs A) {
         for (int w = gg; w < nwaves; w += G) t += gsum[(w * 2 + which) * cpg + c2];
         A.part[(size_t)blockIdx.x * 2 * cin + e] = t;
     }
+    if constexpr (W0) {
+        // ---- the waves' partial tiles (different row steps) are summed in a fixed order; one slab per workgroup
+        __syncthreads();
+        float* red = lds;  // [nwaves][NK0][64 lanes][4] + [nwaves][64] bias partials
+        float* redb = lds + nwaves * NK0 * 256;
+#pragma unroll
+        for (int j = 0; j < NK0; ++j) *reinterpret_cast<cf32x4*>(red + ((wave * NK0 + j) * 64 + lane) * 4) = acc0[j];
+        redb[wave * 64 + lane] = bsum0;
+        __syncthreads();
+        if (wave == 0) {
+            float* pw = A.w0_part + (size_t)blockIdx.x * cin * A.K0;
+#pragma unroll
+            for (int j = 0; j < NK0; ++j) {
+                cf32x4 v = acc0[j];
+                for (int q = 1; q < nwaves; ++q) v += *reinterpret_cast<const cf32x4*>(red + ((q * NK0 + j) * 64 + lane) * 4);
+                const int kcol = j * 16 + l16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 4 * quad + r;
+                    if (co < cin && kcol < A.K0) pw[(size_t)co * A.K0 + kcol] = v[r];
+                }
+            }
+            // bias gradient of layer 0 = column sums of dZ_0: lane (quad, l16) summed channel l16 over its rows
+            float t = 0.f;
+            for (int q = 0; q < nwaves; ++q)
+                t += ((redb[q * 64 + l16] + redb[q * 64 + 16 + l16]) + redb[q * 64 + 32 + l16]) + redb[q * 64 + 48 + l16];
+            if (quad == 0 && l16 < cin) A.w0_bpart[(size_t)blockIdx.x * cin + l16] = t;
+        }
+    }
 }
 
 static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
@@ -1850,6 +1939,19 @@ static size_t cnn_dgrad_plan(CnnDgradArgs& a, int rb) {
     off += (size_t)rb * a.G * 2;
     a.off_gsum = (int)off;
     off += (size_t)8 * 2 * cpg;
+    if (a.w0) {  // zero-bordered raw patches of the chunk [rb][f0 + 2][f0 + 2][cin0]
+        off = (off + 3) & ~(size_t)3;
+        a.cs0 = a.cin0;
+        a.pix_per = (a.f0 + 2) * (a.f0 + 2) * a.cs0;
+        a.off_pix = (int)off;
+        off += (size_t)rb * a.pix_per;
+        a.dpe0 = make_fdiv(a.cin0 * a.f0 * a.f0);
+        a.dff0 = make_fdiv(a.f0 * a.f0);
+        a.df0 = make_fdiv(a.f0);
+        a.dhin0 = make_fdiv(a.hin);
+        const size_t red = (size_t)8 * 2 * 256 + 8 * 64;  // the final tile reduction lives at the start of LDS
+        if (off < red) off = red;
+    }
     // Row tiles -> wave slots: contiguous ranges (one parity class -> one set of taps, so one
     // weight fragment feeds every tile of a range) of about equal cost; a tile costs one unit
     // plus one per tap of the classes it touches (1, 2, 2, 4 taps), <= kDgradTiles per slot.
@@ -1917,6 +2019,16 @@ int cnn_dgrad_supported(const CnnDgradArgs& a0) {
     return cnn_dgrad_rb(a) > 0;
 }
 
+// can the launch that produces dZ_0 also form layer 0's weight gradient? (cin = layer 0's output channels: one
+// 16-wide tile; K0 = 9 * cin0 <= 32: two k tiles)
+// OPT-IN (knob dgrad_w0 = 1): measured SLOWER than the separate first-layer launch on every BASELINE shape (C3 7.68
+// vs 7.59 ms, C4 3.71 vs 3.63, C5 18.45 vs 18.25: DESIGN 4.0c) - the extra phase adds two barriers, a scattered
+// pixel gather and ~4 us of dependent latency to each chunk of a kernel that is a latency chain already, which costs
+// more than the 100 us launch and the dZ_0 round trip it removes.
+int cnn_dgrad_w0_ok(const CnnDgradArgs& a, int cin0, int f0) {
+    return tune_get("dgrad_w0", 0) != 0 && a.cin <= 16 && 9 * cin0 <= 32 && cin0 >= 1 && (f0 - 1) / 2 + 1 == a.hin;
+}
+
 // Persistent grid: as many workgroups as are resident at once (occupancy x CUs), never more than
 // there are chunks.  This is also the number of affine partial rows the kernel writes.
 static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
@@ -1930,14 +2042,15 @@ static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
         num_cu = prop.multiProcessorCount;
     }
     int occ = 0;
+    const size_t key = lds * 2 + (a.w0 ? 1 : 0);  // (the two instantiations differ in registers)
     for (int i = 0; i < occ_n; ++i)
-        if (occ_lds[i] == lds) occ = occ_val[i];
+        if (occ_lds[i] == key) occ = occ_val[i];
     if (!occ) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(cnn_dgrad_kernel), 512, lds) !=
-                hipSuccess || occ < 1)
-            occ = 1;
+        const void* kern = a.w0 ? reinterpret_cast<const void*>(cnn_dgrad_kernel<true>)
+                                     : reinterpret_cast<const void*>(cnn_dgrad_kernel<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds) != hipSuccess || occ < 1) occ = 1;
         if (occ_n < 8) {
-            occ_lds[occ_n] = lds;
+            occ_lds[occ_n] = key;
             occ_val[occ_n++] = occ;
         }
     }
@@ -1950,7 +2063,9 @@ static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
 static void cnn_dgrad_raise_lds() {
     static bool raised = false;
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         raised = true;
     }
@@ -1988,7 +2103,14 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
     a.ts = rec ? d_ts : nullptr;
 #endif
     prof_before(5, st);
-    hipLaunchKernelGGL(cnn_dgrad_kernel, dim3((unsigned)grid), dim3(512), lds, st, a);
+    if (a.w0 && (!a.w0_part || !a.w0_bpart || !a.img || !a.pos)) {
+        set_error("fused CNN layer backward: first-layer weight gradient without its buffers");
+        return MARL_EINVAL;
+    }
+    if (a.w0)
+        hipLaunchKernelGGL(cnn_dgrad_kernel<true>, dim3((unsigned)grid), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL(cnn_dgrad_kernel<false>, dim3((unsigned)grid), dim3(512), lds, st, a);
     prof_after(5, st);
     MARL_LAUNCH_CHECK();
 #ifdef MARL_KERNEL_TS

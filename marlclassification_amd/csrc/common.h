@@ -812,6 +812,16 @@ struct CnnDgradArgs {
     int rb, MT, NT, off_zin, off_da, off_perm, off_stat, off_gsum;
     int tbeg[17];  // row-tile range of wave slot s: [tbeg[s], tbeg[s + 1])
     FDiv dc4o, dc4i, dPin, dcpg, dG;
+    // optional (the launch that produces dZ_0, w0_part != null): layer 0's weight / bias gradient formed in the same
+    // launch from the dZ_0 panel and the raw patch - dZ_0 is then not written when dzin is null
+    const void* img;       // image batch [nb][c_img][H][W] float or uint8
+    const int32_t* pos;    // [rows][2] patch positions (row r reads image r % nb)
+    float* w0_part;        // [workgroups][cin * K0] partial slabs (cin = layer 0's output channels here)
+    float* w0_bpart;       // [workgroups][cin]
+    int w0;                // 1: this launch also forms layer 0's weight gradient (decides the LDS plan)
+    int img_u8, nb, c_img, H, W, cin0, f0, K0;
+    int off_pix, pix_per, cs0;  // filled by the launcher
+    FDiv dpe0, dff0, df0, dhin0;
 #ifdef MARL_KERNEL_TS
     long long* ts;
 #endif
@@ -820,6 +830,7 @@ int cnn_dgrad_supported(const CnnDgradArgs& a);
 int cnn_dgrad_blocks(const CnnDgradArgs& a);      // partial rows the launch writes (persistent grid)
 int cnn_dgrad_blocks_max(const CnnDgradArgs& a);  // its device-independent upper bound
 int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st);
+int cnn_dgrad_w0_ok(const CnnDgradArgs& a, int cin0, int f0);  // (see w0_part)
 
 // ---------------------------------------------------------------------------
 // Convolution weight gradient straight from the activations (cnn.hip): for every patch,

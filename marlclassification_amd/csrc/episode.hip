@@ -340,6 +340,18 @@ static CnnDgradArgs cnn_dgrad_shape(const Dims& d, int l) {
     g.P = d.P[l];
     g.Pin = d.P[l - 1];
     g.G = d.grp[l - 1];
+    // the launch that produces dZ_0 also forms layer 0's weight gradient when the shapes allow it (cnn.hip)
+    if (l == 1 && cnn_dgrad_w0_ok(g, d.ch[0], d.f) && cnn_wgrad_supported(cnn_wgrad_shape(d, 0))) {
+        g.w0 = 1;
+        g.cin0 = d.ch[0];
+        g.f0 = d.f;
+        g.K0 = d.K[0];
+        g.nb = d.nb;
+        g.c_img = d.c_img;
+        g.H = d.H;
+        g.W = d.W;
+        if (!cnn_dgrad_supported(g)) g.w0 = 0;  // (the pixel images do not fit next to the panels: separate launches)
+    }
     return g;
 }
 
@@ -507,6 +519,16 @@ static void make_elayout(const Dims& d, int train, ELayout& e) {
                 }
         }
         upd_tn(d.n_d, 2, nr);
+        if (d.L > 1 && e.dgrad_ok[1]) {  // layer 0's weight gradient out of the dZ_0 launch: one small slab per workgroup
+            const CnnDgradArgs g1 = cnn_dgrad_shape(d, 1);
+            if (g1.w0) {
+                int64_t nb_ = cnn_dgrad_blocks_max(g1);
+                if (nb_ > 2048) nb_ = 2048;  // (persistent grid: occupancy <= 8 workgroups x 256 CUs)
+                const size_t v = (size_t)nb_ * ((size_t)d.ch[1] * d.K[0] + d.ch[1]) * sizeof(float);
+                tns = v > tns ? v : tns;
+                red += v / sizeof(float) + 64 * ((size_t)d.ch[1] * (d.K[0] + 1)) + 192;
+            }
+        }
         for (int l = 0; l < d.L; ++l) {
             if (e.wgrad_ok[l]) {  // per-workgroup partial slabs of the activation-based kernel
                 const size_t v = (size_t)cnn_wgrad_blocks(cnn_wgrad_shape(d, l)) *
@@ -1720,6 +1742,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
         int64_t ldda = d.ld_nin;
         int chw = 1;
         bool have_dz = false;  // DZ[l] already produced by the fused layer backward of layer l+1
+        bool w0_done = false;  // ... which also formed layer 0's weight gradient (dZ_0 never left LDS)
         for (int l = d.L - 1; l >= 0; --l) {
             const int co = d.ch[l + 1];
             const int64_t rows = NR * d.P[l];
@@ -1734,7 +1757,9 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                                               grads[4 * l + 3], 0, st, q));
             }
             have_dz = false;
-            if (c.e.wgrad_ok[l]) {
+            if (l == 0 && w0_done) {
+                // (layer 0's weight and bias gradient came out of the launch that produced dZ_0)
+            } else if (c.e.wgrad_ok[l]) {
                 // dW_l (and db_l) from dZ_l and the layer's input, recomputed from what forward
                 // kept (Z_{l-1} + statistics, or the image patch): no im2col rows in HBM
                 CnnWgradArgs w = cnn_wgrad_shape(d, l);
@@ -1780,16 +1805,43 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                 g.gamma = c.wp(4 * (l - 1) + 2);
                 g.beta = c.wp(4 * (l - 1) + 3);
                 g.dzin = c.at(c.e.DZ[l - 1]);
+                if (g.w0 && !img) g.w0 = 0;  // (the step API has no image batch: layer 0 takes the separate launch)
                 if (c.e.dgrad_ok[l] &&
                     (size_t)cnn_dgrad_blocks(g) * 2 * d.ch[l] <= c.e.part_floats) {
                     RedQueue* q;
-                    g.part = part_scratch(c, cnn_dgrad_blocks(g), d.ch[l], 0, q);
+                    const int nblk = cnn_dgrad_blocks(g);
+                    g.part = part_scratch(c, nblk, d.ch[l], 0, q);
+                    const int co0 = d.ch[l], k0 = d.K[0];
+                    if (g.w0) {  // + layer 0's weight gradient: per-workgroup slabs (tiny: 448 floats each at RESISC)
+                        const size_t fl = (size_t)nblk * ((size_t)co0 * k0 + co0);
+                        g.w0_part = c.at(c.e.TNS);
+                        if (c.rq && c.defer_this(fl * sizeof(float))) {
+                            float* p = c.rq->take(fl);
+                            if (c.rq->rc == MARL_OK) g.w0_part = p;
+                        }
+                        g.w0_bpart = g.w0_part + (size_t)nblk * co0 * k0;
+                        g.img = img;
+                        g.img_u8 = img_u8;
+                        g.pos = c.POSs(0);
+                        g.dzin = nullptr;  // dZ_0 stays in LDS
+                    }
                     MARL_TRY(launch_cnn_dgrad(g, st));
-                    MARL_TRY(launch_reduce_affine(g.part, cnn_dgrad_blocks(g), d.ch[l],
+                    MARL_TRY(launch_reduce_affine(g.part, nblk, d.ch[l],
                                                   grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3], 0, st, q));
+                    if (g.w0) {
+                        if (c.rq && g.w0_part != c.at(c.e.TNS)) {
+                            c.rq->push(g.w0_part, (int64_t)co0 * k0, nblk, co0 * k0, c.gp(0), co0 * k0, k0, c.w.ldp[0], nullptr, 0);
+                            c.rq->push(g.w0_bpart, co0, nblk, co0, grads[1], co0, co0, co0, nullptr, 0);
+                        } else {
+                            MARL_TRY(launch_slab_reduce(g.w0_part, (int64_t)co0 * k0, nblk, c.gp(0), c.w.ldp[0], co0, k0,
+                                                        g.w0_bpart, grads[1], st));
+                        }
+                        w0_done = true;
+                    }
                     have_dz = true;
                     continue;
                 }
+                g.w0 = 0;
                 MARL_TRY(gemm1(c, gemm_prob(dz, co, c.wt(4 * l), p4(co), co, c.at(c.e.DCOLS[l]),
                                             d.ldk[l], (int)rows, d.K[l])));
                 MARL_TRY(launch_col2im(c.at(c.e.DCOLS[l]), d.ldk[l], c.at(c.e.DA[l - 1]), NR,
