@@ -858,7 +858,9 @@ static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st
     dim3 grid((unsigned)cdiv(max_m, BM), (unsigned)cdiv(max_n, LSTM ? 32 : BN), (unsigned)batch.count);
     batch.gx = (int)grid.x;
     batch.gy = (int)grid.y;
-    batch.xcd_map = batch.count == 1 && !LSTM && tune_get("nt_xcd", 1);
+    // XCD-contiguous tile order: single products always; the two-cell LSTM launch by knob (each half of the XCDs then
+    // streams ONE cell's 3.8 MB of weight images - they fit its L2 - at the price of fetching A's row tiles twice)
+    batch.xcd_map = tune_get("nt_xcd", 1) && (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1);
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     batch.safe = tune_get("g3_safe", 0);
     constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
