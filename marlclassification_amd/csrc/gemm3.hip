@@ -1196,15 +1196,17 @@ int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStre
     for (G3TnArgs* q : {&ih, &hh}) {
         q->rows_per_split = plan.rows_per_split;
         q->safe = tune_get("g3_safe", 0) != 0;
-        float* csum = q->csum;
         for (int j0 = 0; j0 < q->nj; j0 += 256) {
             G3TnArgs t = *q;
             t.j_first = j0;
-            t.csum = j0 == 0 ? csum : nullptr;  // (column sums of G: once)
+            t.csum = nullptr;
             if (q->nj - j0 > 128) c.t[n++] = t;
             else last128 = t, have128 = true;
         }
     }
+    // the column sums of G (the bias gradient) ride on the FIRST 256-wide tile, whichever product it belongs to (both
+    // read the same G; the narrow tile's body carries no column-sum accumulators)
+    c.t[0].csum = ih.csum ? ih.csum : hh.csum;
     c.n256 = n;
     if (have128) c.t[n++] = last128;
     c.nt = n;

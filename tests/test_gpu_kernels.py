@@ -372,7 +372,7 @@ def test_gemm_tn_images(device, rows, ni, nj, variant):
 
 
 @pytest.mark.parametrize("rows,ni,nih,nhh", [(32768, 256, 368, 256), (32768 + 96, 512, 624, 256), (32768, 256, 300, 200),
-                                              (65536, 1024, 368, 256)])
+                                              (65536, 1024, 368, 256), (32768, 768, 368, 192), (40000 - 40000 % 32, 300, 80, 256)])
 def test_gemm_tn_images_cell(device, rows, ni, nih, nhh):
     """both weight gradients of an LSTM cell from ONE launch (G's row slabs shared through the L2 of an XCD): against
     float64 within the row-contraction bound, bit-equal to its fully-waited build, column sums = bias gradient,
