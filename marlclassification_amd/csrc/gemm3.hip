@@ -1145,18 +1145,17 @@ G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
     G3TnPlan p;
     p.variant = 5;
     // work per (G tile, row slab) in 256 x 256 units; the split count gives every CU the same number of units
-    const int units2 = 2 * ((nj_ih + 127) / 256 + (nj_hh + 127) / 256) + ((nj_ih % 256 > 0 && nj_ih % 256 <= 128) ? 1 : 0) +
-                       ((nj_hh % 256 > 0 && nj_hh % 256 <= 128) ? 1 : 0);  // in half units
-    (void)units2;
-    int64_t s = tune_get("g3_tn_cell_splits", 64);
-    if (g3_tn_cell_teams(ni, nj_ih, nj_hh) && tune_get("g3_tn_cell_splits", 0) == 0) {
-        // equal workgroups, (ni / 512) (2 n256 + 1) of them per slab: the split count that fills whole rounds of 256
-        const int n256 = ((nj_ih > 128 ? (nj_ih % 256 > 128 || nj_ih % 256 == 0 ? (nj_ih + 255) / 256 : nj_ih / 256) : 0) +
-                          (nj_hh > 128 ? (nj_hh % 256 > 128 || nj_hh % 256 == 0 ? (nj_hh + 255) / 256 : nj_hh / 256) : 0));
-        const int64_t units = (int64_t)(ni / 512) * (2 * n256 + 1);
-        const int64_t rounds = cdiv(units * 64, 256);
-        s = 256 * rounds / units;
-    }
+    // ONE round of equal workgroups: every workgroup of the launch is resident at once (<= 256: one per CU), walks a
+    // long row slab and writes one partial tile - measured against 3 rounds of a third the length (760 workgroups):
+    // C3 7.37 vs 7.47 ms, C5 17.60 vs 17.78 (a third of the partial-slab traffic, no dispatch stagger inside a team);
+    // two rounds: no gain.  Knob g3_tn_cell_splits overrides.
+    const int n256 = ((nj_ih > 128 ? (nj_ih % 256 > 128 || nj_ih % 256 == 0 ? (nj_ih + 255) / 256 : nj_ih / 256) : 0) +
+                      (nj_hh > 128 ? (nj_hh % 256 > 128 || nj_hh % 256 == 0 ? (nj_hh + 255) / 256 : nj_hh / 256) : 0));
+    const int n128 = ((nj_ih % 256 > 0 && nj_ih % 256 <= 128) ? 1 : 0) + ((nj_hh % 256 > 0 && nj_hh % 256 <= 128) ? 1 : 0);
+    const int64_t per_slab = g3_tn_cell_teams(ni, nj_ih, nj_hh) ? (int64_t)(ni / 512) * (2 * n256 + 1)
+                                                                : (int64_t)cdiv(ni, 256) * (n256 + n128);
+    int64_t s = tune_get("g3_tn_cell_splits", 0);
+    if (s <= 0) s = (int64_t)tune_get("g3_tn_cell_rounds", 1) * 256 / (per_slab > 0 ? per_slab : 1);
     const int64_t max_s = cdiv(rows, 256);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
