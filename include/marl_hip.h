@@ -283,7 +283,7 @@ int marl_gemm_tn_images(const void* a3, const void* b3, float* c, int ldc, int n
  * training/trainer.py:115): C_ih [NI, NIH] = G^T U and C_hh [NI, NHH] = G^T H from the images of the gate gradients
  * G [rows, NI], of U [rows, NIH] and of H [rows, NHH]; colsum (nullable) [NI] = column sums of G (the bias
  * gradient).  One launch whose workgroups share G's row slabs through an XCD's L2: G leaves HBM once.
- * marl_gemm_tn_images_cell_scratch returns 0 for shapes outside this plan (NI < 256, rows < 32768, more than four
+ * marl_gemm_tn_images_cell_scratch returns 0 for shapes outside this plan (NI < 256, rows < 8192, more than four
  * column tiles): use marl_gemm_tn_images for those. */
 size_t marl_gemm_tn_images_cell_scratch(int ni, int nih, int nhh, int64_t rows);
 int marl_gemm_tn_images_cell(const void* g3, int ni, const void* u3, int nih, const void* h3, int nhh, int64_t rows,

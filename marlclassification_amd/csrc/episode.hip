@@ -222,8 +222,11 @@ static bool g3_enabled(const Dims& d) {
 // or column passes, g3_tn_plan): only where that form wins - >= 32768 contraction rows (at C4's 8192 rows the
 // fp32-operand kernel is 25 % faster) and at most three column passes on the B side
 static bool g3_tn_enabled(const Dims& d) {
-    return tune_get("g3_lstm", 1) != 0 && tune_get("g3_tn", 1) != 0 &&
-           (tune_get("g3_tn", 1) == 2 || (d.NR >= 32768 && d.nin <= 640 && d.n_b <= 512 && d.n_a <= 512));
+    if (tune_get("g3_lstm", 1) == 0 || tune_get("g3_tn", 1) == 0) return false;
+    if (tune_get("g3_tn", 1) == 2) return true;
+    if (d.nin > 640 || d.n_b > 512 || d.n_a > 512) return false;
+    // (round 5: the one-launch-per-cell form wins from 8 192 rows on - C4 at 32 images per GPU: 3.62 vs 3.69 ms)
+    return d.NR >= 32768 || (g3_tn_cell_ok(4 * d.n_b, d.nin, d.n_b, d.NR) && g3_tn_cell_ok(4 * d.n_a, d.nin, d.n_a, d.NR));
 }
 
 // conv weights whose tiles are whole (16 output channels x 16-deep K steps) get a fragment-order copy

@@ -1121,7 +1121,7 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
 
 // ---- one cell's dW_ih and dW_hh in one launch ---------------------------------------------------------
 bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows) {
-    if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < 32768 || (rows & 31)) return false;
+    if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < tune_get("g3_tn_cell_min_rows", 8192) || (rows & 31)) return false;
     // column tiles: whole 256-wide ones plus at most one remainder of <= 128 columns, per operand
     auto tiles = [](int nj, int& n256, int& n128) {
         n256 = nj / 256;

@@ -372,7 +372,7 @@ def test_gemm_tn_images(device, rows, ni, nj, variant):
 
 
 @pytest.mark.parametrize("rows,ni,nih,nhh", [(32768, 256, 368, 256), (32768 + 96, 512, 624, 256), (32768, 256, 300, 200),
-                                              (65536, 1024, 368, 256), (32768, 768, 368, 192), (40000 - 40000 % 32, 300, 80, 256)])
+                                              (65536, 1024, 368, 256), (32768, 768, 368, 192), (40000 - 40000 % 32, 300, 80, 256), (8192, 1024, 624, 256)])
 def test_gemm_tn_images_cell(device, rows, ni, nih, nhh):
     """both weight gradients of an LSTM cell from ONE launch (G's row slabs shared through the L2 of an XCD): against
     float64 within the row-contraction bound, bit-equal to its fully-waited build, column sums = bias gradient,
@@ -408,7 +408,7 @@ def test_gemm_tn_images_cell(device, rows, ni, nih, nhh):
     assert (c_hh[:, :nhh].cpu().double() - gd.t() @ h.double()).abs().max().item() <= TN_BOUND * _dot_scale(g.t(), h.t())
     assert (cs.cpu().double() - gd.sum(0)).abs().max().item() <= TN_BOUND * g.abs().double().sum(0).max().item() * 2.0 ** -24 * 4
     assert th.equal(c_ih[:, nih:].cpu(), th.zeros(ni, ld_ih - nih)) and th.equal(c_hh[:, nhh:].cpu(), th.zeros(ni, ld_hh - nhh))
-    assert lib.marl_gemm_tn_images_cell_scratch(ni, nih, nhh, 8192) == 0  # (short contractions keep the per-product kernels)
+    assert lib.marl_gemm_tn_images_cell_scratch(ni, nih, nhh, 4096) == 0  # (short contractions keep the per-product kernels)
 
 
 @pytest.mark.parametrize("m,n", [(95, 24), (4096, 384), (7, 1), (300, 1000)])
