@@ -204,14 +204,15 @@ struct WLayout {
 // The image GEMMs (gemm3.hip) take over the large products when every step's row slice starts on an
 // image row block (R % 32 == 0: all BASELINE shapes) and the cells' widths keep 16-byte accesses.
 // (Layout-relevant: the workspaces grow by the images - marl_workspace_sizes after a knob change.)
-// Measured: a gain from cells of >= 128 units on (C3 -1.8 %, C4 -4.8 % per iteration);
-// the 64-unit MNIST shapes lose 4 % to the image writes, so they keep the fp32-operand kernels unless the
-// knob g3_min_units is lowered (the parity fixtures do that to run this path on small shapes too).
+// Measured: round 4 (128-row tile plans only) a gain from cells of >= 128 units on, the 64-unit MNIST shapes lost 4 %
+// to the image writes; round 5, with the small-batch plans (gate-split LSTM launch, 64 x 64 NT tiles), the MNIST
+// shapes gain too - C2 (B = 1024) 0.786 -> 0.755 ms, the same shapes at B = 32 0.614 -> 0.528 ms: on from 64 units
+// (knob g3_min_units; the parity fixtures lower it further to run this path on the odd small shapes too).
 // The MODEL-only part decides the weights workspace (its k16 weight images): that layout must not move
 // with the batch - an epoch's last partial batch or an odd eval batch runs on the weights packed for the
 // previous one.  The batch-dependent part only picks the kernels of a call.
 static bool g3_model_ok(const Dims& d) {
-    const int mu = tune_get("g3_min_units", 128);
+    const int mu = tune_get("g3_min_units", 64);
     return split_mode() && tune_get("g3", 1) != 0 && (d.n_b & 3) == 0 && (d.n_a & 3) == 0 && d.n_b >= mu &&
            d.n_a >= mu;
 }

@@ -117,7 +117,7 @@ class image_path:
         from marlclassification_amd import engine as E
 
         E.tune("g3", 1)
-        E.tune("g3_min_units", 128)
+        E.tune("g3_min_units", 64)
         E.tune("g3_tn", 1)
 
 
