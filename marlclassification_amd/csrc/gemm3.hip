@@ -973,6 +973,7 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
         rc = launch_g3_variant<128, 64, 4, 2, 3, false>(batch, max_m, max_n, st);
     else if (variant == 12)
         rc = launch_g3_variant<64, 64, 2, 2, 3, false>(batch, max_m, max_n, st);
+
     else
         rc = launch_g3_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
     prof_after(1, st);
