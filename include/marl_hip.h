@@ -18,6 +18,10 @@
  *     two workspaces whose sizes marl_workspace_sizes() reports.  Both must be
  *     ZERO-FILLED once by the caller before first use (padding columns inside
  *     them are never written and are read as zeros by the matrix kernels);
+ *   - the WEIGHTS workspace (size and the offset of everything inside it) is a function of the model fields of
+ *     marl_config and of the tuning knobs only - never of batch, nb_agents, nb_steps or the image size: one
+ *     marl_pack_weights serves every batch size until the weights change (an epoch's last partial batch, an
+ *     evaluation batch).  The EPISODE workspace depends on all of them: re-query marl_workspace_sizes;
  *   - return value: 0 on success, a negative MARL_E* code otherwise; nothing
  *     throws across the ABI.  marl_last_error() gives a thread-local message;
  *   - one process drives one GPU (the launch contract of bench.py / train.py): the one-off
