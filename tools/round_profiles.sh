@@ -40,6 +40,8 @@ for c in c2 c4 c5; do
   prof $c --config $c --steps 10 --warmup 3
 done
 prof c3_rollout_only --rollout-only --steps 10 --warmup 3
+# the strong-scaling operating point of the C3 shapes (256 images over 8 GPUs = 32 per GPU)
+python3 bench.py --batch 32 --no-cpu-baseline 2>/dev/null | grep '"metric"' > $P/${R}_bench_c3_b32.json
 # the kernel-level lab records, regenerated from THIS tree (a stale one was cited as proof)
 python3 tools/g3_lab.py > gpurun_out/${R}_g3_lab.log 2>&1 && cp gpurun_out/g3_lab.json $P/${R}_g3_lab.json
 python3 - <<PY
