@@ -2751,7 +2751,7 @@ static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
             const size_t off_dz = 3 * in_plane;
             const size_t off_tab = off_dz + 3 * (size_t)Mpad * a.zs * 2;
             size_t tot = off_tab + (size_t)Mpad * 4;
-            if (tot < 32768 + 0) tot = 32768;  // tile reduction / bias reduction scratch
+            if (tot < 32768) tot = 32768;  // the final tile reduction (8 waves x 64 lanes x 16 floats) lives at the start of LDS
             tot = (tot + 15) & ~(size_t)15;
             if (tot > (size_t)lds_cap_kb * 1024 && rb > 1) continue;
             if (tot > 150 * 1024) break;

@@ -1121,38 +1121,40 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
 }
 
 // ---- one cell's dW_ih and dW_hh in one launch ---------------------------------------------------------
+// column tiles of one operand: whole 256-wide ones (a remainder of more than 128 columns takes one too) plus at most
+// one narrow tile for a remainder of <= 128 columns
+static void tn_cell_tiles(int nj, int& n256, int& n128) {
+    n256 = nj / 256;
+    const int rem = nj - n256 * 256;
+    n128 = 0;
+    if (rem > 128) ++n256;
+    else if (rem > 0) n128 = 1;
+}
 bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows) {
     if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < tune_get("g3_tn_cell_min_rows", 8192) || (rows & 31)) return false;
-    // column tiles: whole 256-wide ones plus at most one remainder of <= 128 columns, per operand
-    auto tiles = [](int nj, int& n256, int& n128) {
-        n256 = nj / 256;
-        const int rem = nj - n256 * 256;
-        n128 = 0;
-        if (rem > 128) ++n256;
-        else if (rem > 0) n128 = 1;
-    };
     int a256, a128, b256, b128;
-    tiles(nj_ih, a256, a128);
-    tiles(nj_hh, b256, b128);
+    tn_cell_tiles(nj_ih, a256, a128);
+    tn_cell_tiles(nj_hh, b256, b128);
     return a128 + b128 <= 1 && a256 + b256 + a128 + b128 <= kMaxTnCell && a256 + b256 >= 1;
 }
 // teams (see the kernel): a narrow last tile exists and G's 256-column tiles pair up
 static bool g3_tn_cell_teams(int ni, int nj_ih, int nj_hh) {
-    const int r1 = nj_ih % 256, r2 = nj_hh % 256;
-    const bool narrow = (r1 > 0 && r1 <= 128) || (r2 > 0 && r2 <= 128);
-    return tune_get("g3_tn_cell_teams", 1) != 0 && narrow && ni % 512 == 0;
+    int a256, a128, b256, b128;
+    tn_cell_tiles(nj_ih, a256, a128);
+    tn_cell_tiles(nj_hh, b256, b128);
+    return tune_get("g3_tn_cell_teams", 1) != 0 && a128 + b128 == 1 && ni % 512 == 0;
 }
 G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
     G3TnPlan p;
     p.variant = 5;
-    // work per (G tile, row slab) in 256 x 256 units; the split count gives every CU the same number of units
     // ONE round of equal workgroups: every workgroup of the launch is resident at once (<= 256: one per CU), walks a
     // long row slab and writes one partial tile - measured against 3 rounds of a third the length (760 workgroups):
     // C3 7.37 vs 7.47 ms, C5 17.60 vs 17.78 (a third of the partial-slab traffic, no dispatch stagger inside a team);
     // two rounds: no gain.  Knob g3_tn_cell_splits overrides.
-    const int n256 = ((nj_ih > 128 ? (nj_ih % 256 > 128 || nj_ih % 256 == 0 ? (nj_ih + 255) / 256 : nj_ih / 256) : 0) +
-                      (nj_hh > 128 ? (nj_hh % 256 > 128 || nj_hh % 256 == 0 ? (nj_hh + 255) / 256 : nj_hh / 256) : 0));
-    const int n128 = ((nj_ih % 256 > 0 && nj_ih % 256 <= 128) ? 1 : 0) + ((nj_hh % 256 > 0 && nj_hh % 256 <= 128) ? 1 : 0);
+    int a256, a128, b256, b128;
+    tn_cell_tiles(nj_ih, a256, a128);
+    tn_cell_tiles(nj_hh, b256, b128);
+    const int n256 = a256 + b256, n128 = a128 + b128;
     const int64_t per_slab = g3_tn_cell_teams(ni, nj_ih, nj_hh) ? (int64_t)(ni / 512) * (2 * n256 + 1)
                                                                 : (int64_t)cdiv(ni, 256) * (n256 + n128);
     int64_t s = tune_get("g3_tn_cell_splits", 0);
