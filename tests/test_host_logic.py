@@ -47,6 +47,37 @@ def test_param_table_matches_reference_shapes(tag):
     assert used == total
 
 
+def test_weights_workspace_layout_is_independent_of_the_batch():
+    """the weights workspace (size and the offset of every packed copy inside it) is a function
+    of the model and the knobs only.  Batch 256 (R = 4096: image GEMMs on), 255 (R % 32 != 0: off) and 1, 3 agents
+    instead of 16, another image size and step count: same bytes, same offsets - while the kernel family does change
+    (marl_plan_query).  (Host-side layout code only: runs without a GPU.)"""
+    from marlclassification_amd import _lib
+
+    lib = _lib.load()
+    spec = model_spec(CASES["g4_resisc_b2"])
+    seen = {}
+    for na, nb, ns, hw in ((16, 256, 16, 256), (16, 255, 16, 256), (16, 1, 16, 256), (3, 7, 2, 64)):
+        mc = spec.config(na, nb, ns, 3, hw, hw)
+        wb = C.c_size_t()
+        assert lib.marl_workspace_sizes(C.byref(mc), 1, C.byref(wb), None) == 0
+        offs = []
+        for name in ("LB_WIH", "LA_WHH", "POL_W0", "PRE_W1"):
+            off, ld = C.c_int64(0), C.c_int(0)
+            assert lib.marl_debug_buffer(C.byref(mc), 1, f"WP{_lib.P[name]}".encode(), 0, C.byref(off), C.byref(ld)) == 0
+            offs.append((off.value, ld.value))
+        g3, g3m = C.c_int(-1), C.c_int(-1)
+        assert lib.marl_plan_query(C.byref(mc), 1, b"g3", C.byref(g3)) == 0
+        assert lib.marl_plan_query(C.byref(mc), 1, b"g3_model", C.byref(g3m)) == 0
+        seen[(na, nb)] = (wb.value, tuple(offs), g3.value, g3m.value)
+    sizes = {v[0] for v in seen.values()}
+    layouts = {v[1] for v in seen.values()}
+    assert len(sizes) == 1 and len(layouts) == 1, seen
+    assert seen[(16, 256)][2] == 1 and seen[(16, 255)][2] == 0 and seen[(16, 1)][2] == 0  # R % 32 decides the kernels
+    assert all(v[3] == 1 for v in seen.values())  # ... never the weights workspace
+    assert lib.marl_plan_query(C.byref(spec.config(16, 4, 2, 3, 64, 64)), 1, b"no_such_key", C.byref(C.c_int())) != 0
+
+
 def test_workspace_sizes_and_config_validation():
     from marlclassification_amd import _lib
 
