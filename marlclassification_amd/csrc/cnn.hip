@@ -1557,19 +1557,41 @@ __global__ __launch_bounds__(512, W0 ? 4 : 1) void cnn_dgrad_kernel(const CnnDgr
         }
         for (int idx = tid; idx < nrow * G * 2; idx += nthreads) gstat[idx] = A.gst[row0 * G * 2 + idx];
         if constexpr (W0) {  // raw patches of the chunk -> interior of the zero-bordered images [lr][y + 1][x + 1][ci]
+            // Batches of kU elements per thread with every load of a batch in flight at once (positions first, then
+            // pixels; clamped indices, predicated LDS writes) instead of two dependent global round trips per element.
+            // (Measured: the fused form still loses to the separate first-layer launch - C3 +0.08...0.16 ms, C5 +0.16,
+            // C4 +0.06 - so the gather was not what costs; see cnn_dgrad_w0_ok.)
             float* Pix = lds + A.off_pix;
-            const int f0 = A.f0, ff = f0 * f0, pe = A.cin0 * ff;
+            const int f0 = A.f0, ff = f0 * f0, pe = A.cin0 * ff, tot = nrow * pe;
             const int64_t plane = (int64_t)A.c_img * A.H * A.W;
             const float* imgf = static_cast<const float*>(A.img);
             const unsigned char* imgb = static_cast<const unsigned char*>(A.img);
-            for (int idx = tid; idx < nrow * pe; idx += nthreads) {
-                const int lr = fdiv(idx, A.dpe0), e = idx - lr * pe;
-                const int ci = fdiv(e, A.dff0), e2 = e - ci * ff;
-                const int iy = fdiv(e2, A.df0), ix = e2 - iy * f0;
-                const int64_t r = row0 + lr;
-                const int p0 = A.pos[r * 2], p1 = A.pos[r * 2 + 1];
-                const int64_t off = (r % A.nb) * plane + (int64_t)(ci * A.H + p0 + iy) * A.W + p1 + ix;
-                Pix[lr * A.pix_per + ((iy + 1) * (f0 + 2) + ix + 1) * A.cs0 + ci] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
+            constexpr int kU = 4;
+            for (int base = tid; base < tot; base += kU * nthreads) {
+                int lo[kU], p0[kU], p1[kU], go[kU], img_i[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    int idx = base + u * nthreads;
+                    idx = idx < tot ? idx : tot - 1;
+                    const int lr = fdiv(idx, A.dpe0), e = idx - lr * pe;
+                    const int ci = fdiv(e, A.dff0), e2 = e - ci * ff;
+                    const int iy = fdiv(e2, A.df0), ix = e2 - iy * f0;
+                    const int64_t r = row0 + lr;
+                    p0[u] = A.pos[r * 2];
+                    p1[u] = A.pos[r * 2 + 1];
+                    img_i[u] = (int)(r % A.nb);
+                    go[u] = (ci * A.H + iy) * A.W + ix;
+                    lo[u] = lr * A.pix_per + ((iy + 1) * (f0 + 2) + ix + 1) * A.cs0 + ci;
+                }
+                float pv[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int64_t off = img_i[u] * plane + (int64_t)p0[u] * A.W + p1[u] + go[u];
+                    pv[u] = A.img_u8 ? (float)imgb[off] / 255.0f : imgf[off];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u)
+                    if (base + u * nthreads < tot) Pix[lo[u]] = pv[u];
             }
         }
     };
