@@ -3,6 +3,8 @@ import os, sys
 import torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marlclassification_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libmarl_abl.so")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from g3_lab import image, padded, timeit, p4, lib, check, dev  # noqa
 
 NAMES = {0: "product", 1: "safe", 2: "no-dma", 3: "no-mfma", 4: "blockmajor", 5: "no-dsread"}
