@@ -37,6 +37,27 @@ __device__ __forceinline__ void wait_vm() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// LDS-DMA by inline asm (round 6).  hipcc's waitcnt pass treats the transposing LDS read intrinsic
+// (ds_read_b64_tr_b16) as an LDS access that may collide with a pending `buffer_load ... lds` and puts
+// `s_waitcnt vmcnt(0)` in front of the first such read that follows an LDS-DMA builtin - in the row-contraction
+// kernels that drained the whole ring once per K step, right behind the issue of the newest stage (every step paid
+// a full memory round trip: 192 us against 132 us of matrix work, profiles/r06_clock_tn_ablate.csv; plain
+// ds_read_b128 - the NT kernels - are not treated that way).  An asm-issued DMA is invisible to that pass; these
+// kernels count vmcnt by hand anyway (wait_vm).  m0 = LDS byte address of the 1 KB this wave-instruction fills.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return i32x4{(int)__builtin_amdgcn_readfirstlane((unsigned)a), (int)(__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffff),
+                 0x7fffffff, 0x00020000};
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 }  // namespace
 
 // BM x BN tile, WM x WN waves (wave tile (BM / WM) x (BN / WN) in 32 x 32 blocks), NST ring stages.
@@ -486,7 +507,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
 // DB: fragments double-buffered in registers (step s + 1 read while step s multiplies, NST - 2 steps in
 // flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
 // fragments of step s are read right behind the barrier, NST - 1 steps in flight.
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0, bool CS = true>
+// PIPE (round 6): the phase-pipelined step - see the block comment at its loop below.
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0, bool CS = true, bool PIPE = false>
 __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsigned bx, int j0, unsigned bz, bool first_col_tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WI * WJ;
@@ -525,23 +547,22 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
         voff[i] = cs * kImgChunkBytes + (slot ^ ((csl & 1) << 2)) * kImgRowBytes + pw * 16;
     }
     const int a_blk = P.a_steps * kImgChunkBytes, b_blk = P.b_steps * kImgChunkBytes;
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(P.a3) + (size_t)((P.a_row0 + r_begin) >> 5) * a_blk, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(P.b3) + (size_t)((P.b_row0 + r_begin) >> 5) * b_blk, 0, 0x7fffffff, 0x00020000);
+    const i32x4 rA = dma_rsrc(P.a3 + (size_t)((P.a_row0 + r_begin) >> 5) * a_blk);
+    const i32x4 rB = dma_rsrc(P.b3 + (size_t)((P.b_row0 + r_begin) >> 5) * b_blk);
+    const unsigned sm_lds = (unsigned)reinterpret_cast<unsigned long long>((lds_ptr)sm);
+    // wave w issues instructions t = w + NW i: with A_INS a multiple of NW, instruction i of EVERY wave belongs to the
+    // same operand (no per-instruction branch on the resource)
+    constexpr bool A_STATIC = A_INS % NW == 0;
     int gi = 0, islot = 0;
     auto issue = [&]() {
         const int half = (gi & 1) * CS_BYTES;  // rows 0..15 / 16..31 of the row block gi / 2
         const int soffA = (gi >> 1) * a_blk + half, soffB = (gi >> 1) * b_blk + half;
-        char* base = sm + islot * ST_BYTES;
+        const unsigned base = sm_lds + islot * ST_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NI_HI; ++i) {
-            const int t = wave + NW * i;
             if (i == NI_LO && !extra_i) break;
-            if (t < A_INS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr)(base + t * 1024), 16, voff[i], soffA, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr)(base + t * 1024), 16, voff[i], soffB, 0, 0);
+            const bool isA = A_STATIC ? i < A_INS / NW : wave + NW * i < A_INS;
+            dma16(isA ? rA : rB, base + NW * i * 1024, voff[i], isA ? soffA : soffB);
         }
         ++gi;
         islot = islot + 1 == NST ? 0 : islot + 1;
@@ -572,7 +593,8 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;  // bf16 1.0
 
-    bf16x8 fa0[3][TM], fb0[3][TN], fa1[DB ? 3 : 1][DB ? TM : 1], fb1[DB ? 3 : 1][DB ? TN : 1];
+    bf16x8 fa0[PIPE ? 1 : 3][PIPE ? 1 : TM], fb0[PIPE ? 1 : 3][PIPE ? 1 : TN], fa1[DB && !PIPE ? 3 : 1][DB && !PIPE ? TM : 1],
+        fb1[DB && !PIPE ? 3 : 1][DB && !PIPE ? TN : 1];
 #define G3T_FRAG(p0_, p1_, off_)                                                                     \
     __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p0_) + (off_))),    \
                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)((p1_) + (off_))), 0, 1, 2, 3, 4, 5, 6, 7)
@@ -619,6 +641,123 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
         ++s;                                                                                         \
     }
 
+    if constexpr (PIPE) {
+        // ---- phase-pipelined step (round 6).  The one-fragment-set loop below runs
+        // [barrier] [issue DMA] [read ALL fragments of the step] [48 MFMAs]: the eight waves of the workgroup pass
+        // the barrier together, so every SIMD's matrix pipe idles while both of its waves issue LDS-DMA and wait
+        // for 36 transposing reads (measured: 192 us against 132 us for the same launch with neither, 256
+        // workgroups - profiles/r06_clock_tn_ablate.csv).  Here a step is cut into NP phases, one per 32-column
+        // block of the WIDER side of the wave tile ("outer" operand, one block = 3 fragments live at a time, two
+        // buffers); the narrower side's fragments ("inner", 3 x NIN) stay for the whole step and have a second set
+        // that receives step s + 1.  Every read and every LDS-DMA instruction sits between MFMAs of the phase
+        // BEFORE its data is needed (sched_group_barrier pins the interleave), so the pipe only drains at the two
+        // barriers of a step:
+        //   B0 (step boundary): all reads of slot s - 1 are done          -> DMA of step s + NST - 1 goes there
+        //   B1 (mid step):      the DMA of step s + 1 has landed (vmcnt)  -> its fragments are read in the 2nd half
+        // NST - 2 steps of DMA stay in flight across B1.  Per accumulator the six products of a step keep the
+        // order of the loop below: results are bit-identical (tested against the fully-waited build).
+        constexpr bool OJ = TN >= TM;
+        constexpr int NP = OJ ? TN : TM, NIN = OJ ? TM : TN;
+        static_assert(NP % 2 == 0 && NST >= 3 && (!CS || OJ), "phase pipeline: even phase count, >= 3 stages");
+        const char* lI0 = OJ ? lA0 : lB0;
+        const char* lI1 = OJ ? lA1 : lB1;
+        const char* lO0 = OJ ? lB0 : lA0;
+        const char* lO1 = OJ ? lB1 : lA1;
+        bf16x8 fi0[3][NIN], fi1[3][NIN], fo0[3], fo1[3];
+#define TP_LOAD_IN(dst_, so_, p_lo_, p_hi_)                                                           \
+        _Pragma("unroll") for (int p = (p_lo_); p < (p_hi_); ++p)                                     \
+            _Pragma("unroll") for (int b = 0; b < NIN; ++b)                                            \
+                dst_[p][b] = G3T_FRAG(lI0, lI1, (so_) + b * 2 * CS_BYTES + p * 32);
+#define TP_LOAD_OUT(dst_, so_, ob_)                                                                   \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) dst_[p] = G3T_FRAG(lO0, lO1, (so_) + (ob_) * 2 * CS_BYTES + p * 32);
+#define TP_P(in_, out_, ob_, pa_, pb_)                                                                \
+        _Pragma("unroll") for (int b = 0; b < NIN; ++b) {                                             \
+            if constexpr (OJ)                                                                         \
+                acc[b][ob_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in_[pa_][b], out_[pb_], acc[b][ob_], 0, 0, 0); \
+            else                                                                                      \
+                acc[ob_][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(out_[pa_], in_[pb_][b], acc[ob_][b], 0, 0, 0); \
+        }
+#define TP_MMA(in_, out_, ob_)                                                                        \
+        TP_P(in_, out_, ob_, 1, 1) TP_P(in_, out_, ob_, 0, 2) TP_P(in_, out_, ob_, 2, 0)              \
+        TP_P(in_, out_, ob_, 0, 1) TP_P(in_, out_, ob_, 1, 0) TP_P(in_, out_, ob_, 0, 0)
+        // interleave of one phase: `nr_` transposing reads two per MFMA, `nv_` LDS-DMA pieces one per MFMA behind
+        // them, the remaining MFMAs of the phase (6 NIN in all, + `xm_` column-sum MFMAs) back to back
+#define TP_SCHED(nr_, nv_, xm_)                                                                       \
+        {                                                                                             \
+            _Pragma("unroll") for (int q = 0; q < ((nr_) + 1) / 2; ++q) {                             \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+            }                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < (nv_); ++q) {                                       \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                                    \
+            }                                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NIN + (xm_) - ((nr_) + 1) / 2 - (nv_), 0); \
+        }
+        // phase ph of step s: its outer block sits in buffer ph & 1; the other buffer receives block ph + 1 (the
+        // last phase: block 0 of step s + 1); the 2nd-half phases also fill the other inner set
+#define TP_PHASE(ina_, inb_, ph_, MAIN_)                                                              \
+        {                                                                                             \
+            constexpr int ph = (ph_);                                                                 \
+            constexpr bool second = ph >= NP / 2, last = ph == NP - 1;                                \
+            constexpr int h2 = NP / 2, pl = (NP == 2 || ph == h2) ? 0 : 2, phi = NP == 2 ? 3 : (ph == h2 ? 2 : 3); /* inner planes read in this phase */ \
+            const bool nxt = MAIN_ || s + 1 < S;                                                      \
+            if constexpr (!last) {                                                                    \
+                if constexpr (ph & 1) { TP_LOAD_OUT(fo0, so, ph + 1) } else { TP_LOAD_OUT(fo1, so, ph + 1) } \
+            } else if (nxt) { TP_LOAD_OUT(fo0, sn, 0) }                                               \
+            if constexpr (second) { if (nxt) { TP_LOAD_IN(inb_, sn, pl, phi) } }                      \
+            if constexpr (ph & 1) { TP_MMA(ina_, fo1, ph) } else { TP_MMA(ina_, fo0, ph) }            \
+            if constexpr (CS && ph == 0) { /* (CS bodies always form the column sums: the caller picks CS by do_csum) */ \
+                _Pragma("unroll") for (int p = 2; p >= 0; --p)                                        \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                    \
+                        accs[CS ? i : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ina_[p][CS ? i : 0], ones, accs[CS ? i : 0], 0, 0, 0); \
+            }                                                                                         \
+            if (MAIN_) TP_SCHED(6 + (second ? 2 * NIN * (phi - pl) : 0), ph == 0 ? NI_HI : 0, CS && ph == 0 ? 3 * TM : 0) \
+        }
+#define TP_BODY(ina_, inb_, MAIN_)                                                                    \
+        {                                                                                             \
+            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): my reads of slot s - 1 (and of step s's first fragments) */ \
+            __builtin_amdgcn_s_barrier();       /* B0 */                                              \
+            const int rn = rs + 1 == NST ? 0 : rs + 1;                                                \
+            const int so = rs * ST_BYTES, sn = rn * ST_BYTES;                                         \
+            if (MAIN_ || gi < S) issue();                                                             \
+            TP_PHASE(ina_, inb_, 0, MAIN_)                                                            \
+            if constexpr (NP == 4) TP_PHASE(ina_, inb_, 1, MAIN_)                                     \
+            if (MAIN_ && !P.safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                            \
+            __builtin_amdgcn_s_barrier();       /* B1 */                                              \
+            if constexpr (NP == 4) { TP_PHASE(ina_, inb_, 2, MAIN_) TP_PHASE(ina_, inb_, 3, MAIN_) }  \
+            else TP_PHASE(ina_, inb_, 1, MAIN_)                                                       \
+            rs = rn;                                                                                  \
+            ++s;                                                                                      \
+        }
+        static_assert(NP == 2 || NP == 4, "phase pipeline: 2 or 4 phases");
+        if (S > 0) {
+#pragma unroll
+            for (int g = 0; g < NST - 1; ++g)
+                if (g < S) issue();
+            if (!P.safe && S >= NST - 1) { G3T_WAIT(NST - 2) } else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            int s = 0, rs = 0;
+            TP_LOAD_IN(fi0, 0, 0, 3)
+            TP_LOAD_OUT(fo0, 0, 0)
+            while (gi + 1 < S) {  // two steps per trip (the inner sets alternate): both have a step to issue
+                TP_BODY(fi0, fi1, true)
+                TP_BODY(fi1, fi0, true)
+            }
+            while (s + 1 < S) {
+                TP_BODY(fi0, fi1, false)
+                TP_BODY(fi1, fi0, false)
+            }
+            if (s < S) TP_BODY(fi0, fi1, false)
+        }
+#undef TP_BODY
+#undef TP_PHASE
+#undef TP_SCHED
+#undef TP_MMA
+#undef TP_P
+#undef TP_LOAD_OUT
+#undef TP_LOAD_IN
+    } else
     if (S > 0 && DB) {
 #pragma unroll
         for (int g = 0; g < NST; ++g)
@@ -714,34 +853,46 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #endif
 }
 
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(WI* WJ * 64, 2) void gemm_tn3_kernel(const G3TnArgs P) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (P.gx > 0) xcd_tile(P.gx, P.gy, P.gz, bx, by, bz);
-    gemm_tn3_body<BI, BJ, WI, WJ, NST, DB, ABL>(P, sm, bx, P.j_first + (int)by * BJ, bz, by == 0);
+    if constexpr (PIPE) {  // (the pipelined body forms the column sums unconditionally when it is compiled with them)
+        if (P.csum != nullptr && by == 0)
+            gemm_tn3_body<BI, BJ, WI, WJ, NST, DB, ABL, true, true>(P, sm, bx, P.j_first + (int)by * BJ, bz, true);
+        else
+            gemm_tn3_body<BI, BJ, WI, WJ, NST, DB, ABL, false, true>(P, sm, bx, P.j_first + (int)by * BJ, bz, false);
+    } else
+        gemm_tn3_body<BI, BJ, WI, WJ, NST, DB, ABL, true, false>(P, sm, bx, P.j_first + (int)by * BJ, bz, by == 0);
 }
 
 // "column passes": a workgroup owns a 256-column tile of A and a row slab and walks ALL columns of B in
 // 256-wide passes with a 128-wide last pass when at most 128 columns remain - no half-empty 256 x 256
 // tile (NJ = 368 -> 256 + 128, NJ = 624 -> 256 + 256 + 128), equal work per workgroup.  A's slab is
 // re-read by every pass (L2 / MALL).
+template <bool PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_tn3_passes_kernel(const G3TnArgs P) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     unsigned bx = blockIdx.x, by = 0, bz = blockIdx.z;
     if (P.gx > 0) xcd_tile(P.gx, 1, P.gz, bx, by, bz);
     for (int j0 = 0; j0 < P.nj; j0 += 256) {
         if (j0 > 0) __syncthreads();  // the epilogue panels of the previous pass live in the ring
-        if (P.nj - j0 > 128)
-            gemm_tn3_body<256, 256, 4, 2, 3, false>(P, sm, bx, j0, bz, j0 == 0);
-        else
-            gemm_tn3_body<256, 128, 4, 2, 3, false>(P, sm, bx, j0, bz, j0 == 0);
+        const bool cs = P.csum != nullptr && j0 == 0;
+        if (P.nj - j0 > 128) {
+            if (PIPE && !cs) gemm_tn3_body<256, 256, 4, 2, 3, false, 0, false, PIPE>(P, sm, bx, j0, bz, false);
+            else gemm_tn3_body<256, 256, 4, 2, 3, false, 0, true, PIPE>(P, sm, bx, j0, bz, j0 == 0);
+        } else {
+            if (PIPE && !cs) gemm_tn3_body<256, 128, 4, 2, 3, false, 0, false, PIPE>(P, sm, bx, j0, bz, false);
+            else gemm_tn3_body<256, 128, 4, 2, 3, false, 0, true, PIPE>(P, sm, bx, j0, bz, j0 == 0);
+        }
     }
 }
 
 // One LSTM cell's two weight gradients in one launch (common.h, G3TnCell): workgroup = (row slab, 256-column
 // tile of G, column tile k of [U | H]), k fastest in the XCD-contiguous order - the nt workgroups that read the
 // same slab of G are dispatched next to each other on one XCD and walk it together.
+template <bool PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_tn3_cell_kernel(const G3TnCell P) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     unsigned bx, by, bz;
@@ -781,10 +932,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn3_cell_kernel(const G3TnCell P)
         xcd_tile(P.gx, P.nt, P.gz, bx, by, bz);
     }
     const G3TnArgs& Q = P.t[by];
-    if ((int)by < P.n256)
-        gemm_tn3_body<256, 256, 4, 2, 3, false>(Q, sm, bx, Q.j_first, bz, Q.csum != nullptr);
-    else
-        gemm_tn3_body<256, 128, 4, 2, 3, false>(Q, sm, bx, Q.j_first, bz, false);
+    if ((int)by < P.n256) {
+        if (PIPE && Q.csum == nullptr) gemm_tn3_body<256, 256, 4, 2, 3, false, 0, false, PIPE>(Q, sm, bx, Q.j_first, bz, false);
+        else gemm_tn3_body<256, 256, 4, 2, 3, false, 0, true, PIPE>(Q, sm, bx, Q.j_first, bz, Q.csum != nullptr);
+    } else
+        gemm_tn3_body<256, 128, 4, 2, 3, false, 0, false, PIPE>(Q, sm, bx, Q.j_first, bz, false);
 }
 
 // ---------------------------------------------------------------------------
@@ -1021,11 +1173,14 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
     return rc;
 }
 
-template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0>
+// knob g3_tn_pipe (default 1): the phase-pipelined step of the 256-column row-contraction bodies (round 6)
+static bool tn_pipe() { return tune_get("g3_tn_pipe", 1) != 0; }
+
+template <int BI, int BJ, int WI, int WJ, int NST, bool DB, int ABL = 0, bool PIPE = false>
 static int launch_tn3_variant(const G3TnArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NST * ((BI + BJ) / 16) * 16 * kImgRowBytes;
     static_assert(lds <= 160 * 1024 && (size_t)WI * WJ * 32 * 36 * 4 <= lds, "LDS ring / epilogue panels");
-    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST, DB, ABL>;
+    auto kern = gemm_tn3_kernel<BI, BJ, WI, WJ, NST, DB, ABL, PIPE>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1098,11 +1253,14 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
         constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;  // the 256 x 256 ring covers the 256 x 128 one
         static bool raised = false;
         if (!raised) {
-            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_passes_kernel),
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_passes_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_passes_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             raised = true;
         }
-        hipLaunchKernelGGL(gemm_tn3_passes_kernel, grid, dim3(512), lds, st, a);
+        if (tn_pipe()) hipLaunchKernelGGL(gemm_tn3_passes_kernel<true>, grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(gemm_tn3_passes_kernel<false>, grid, dim3(512), lds, st, a);
         rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
     } else if (plan.variant == 1)
         rc = launch_tn3_variant<256, 128, 4, 2, 4, true>(a, grid, st);
@@ -1112,6 +1270,8 @@ int launch_gemm_tn3(G3TnArgs a, const G3TnPlan& plan, hipStream_t st) {
     else if (plan.variant == 3 && a.abl == 3) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 3>(a, grid, st);
     else if (plan.variant == 3 && a.abl == 4) rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 4>(a, grid, st);
 #endif
+    else if (plan.variant == 3 && tn_pipe())
+        rc = launch_tn3_variant<256, 256, 4, 2, 3, false, 0, true>(a, grid, st);
     else if (plan.variant == 3)
         rc = launch_tn3_variant<256, 256, 4, 2, 3, false>(a, grid, st);
     else
@@ -1220,12 +1380,15 @@ int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStre
     constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;
     static bool raised = false;
     if (!raised) {
-        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_cell_kernel),
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_cell_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn3_cell_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         raised = true;
     }
     prof_before(2, st);
-    hipLaunchKernelGGL(gemm_tn3_cell_kernel, dim3(total), dim3(512), lds, st, c);
+    if (tn_pipe()) hipLaunchKernelGGL(gemm_tn3_cell_kernel<true>, dim3(total), dim3(512), lds, st, c);
+    else hipLaunchKernelGGL(gemm_tn3_cell_kernel<false>, dim3(total), dim3(512), lds, st, c);
     const int rc = hipGetLastError() == hipSuccess ? MARL_OK : MARL_EHIP;
     prof_after(2, st);
     return rc;

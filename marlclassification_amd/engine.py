@@ -185,6 +185,10 @@ class HipEngine:
         # bumped whenever the weights workspace is (re)allocated: its packed copies are gone and whoever
         # packed last (FusedA2C, ModelsWrapper.ensure_packed) must pack again before the next call
         self.weights_generation = 0
+        # what pack() last filled: the generation it packed into and the tensors it packed from (a
+        # direct user doing pack -> tune -> forward used to get a freshly ZEROED weights workspace, silently)
+        self._packed_generation: Optional[int] = None
+        self._packed_params: Optional[Dict[str, th.Tensor]] = None
         self._ews: Dict[Tuple, th.Tensor] = {}
         self._cfg_key: Optional[Tuple] = None
         self.cfg: Optional[MarlConfig] = None
@@ -232,6 +236,18 @@ class HipEngine:
             self._wws_bytes = wb
             self.weights_generation += 1
         return self._wws
+
+    def packed_weights_ws(self) -> th.Tensor:
+        """The weights workspace for a compute call: if a knob change dropped the buffer pack() filled, the
+        parameters of the last pack() are packed again into the new layout (their CURRENT values - they are the
+        caller's live tensors); with nothing ever packed the call fails instead of running on zeros."""
+        wws = self.weights_ws()
+        if self._packed_generation != self.weights_generation:
+            if self._packed_params is None:
+                raise RuntimeError("HipEngine: no weights packed - call pack(params) before a compute call")
+            self.pack(self._packed_params)
+            wws = self.weights_ws()
+        return wws
 
     def weights_token(self) -> int:
         """Generation of the weights workspace AFTER applying pending invalidations (callers compare it
@@ -293,6 +309,8 @@ class HipEngine:
         check(self.lib.marl_pack_weights(C.byref(self.cfg), self._table(params), wws.data_ptr(), _nbytes(wws),
                                          _stream(self.device)))
         self.pack_generation += 1
+        self._packed_generation = self.weights_generation
+        self._packed_params = params
 
     def episode_forward(
         self, img: th.Tensor, pos0: th.Tensor, h0: th.Tensor, c0: th.Tensor, hc0: th.Tensor,
@@ -320,7 +338,7 @@ class HipEngine:
         seed, offset = rng if rng is not None else (0, 0)
         if out is None:  # (graph capture passes persistent output tensors: nothing may allocate)
             out = self.new_outputs()
-        wws, ews = self.weights_ws(), (ws if ws is not None else self.episode_ws(train))
+        wws, ews = self.packed_weights_ws(), (ws if ws is not None else self.episode_ws(train))
         check(self.lib.marl_episode_forward(
             C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             img.data_ptr(), pos0.data_ptr(), h0.data_ptr(), c0.data_ptr(), hc0.data_ptr(),
@@ -364,7 +382,7 @@ class HipEngine:
             gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
             gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
             gv = None if g_values is None else _need(g_values, th.float32, "g_values")
-            wws = self.weights_ws()
+            wws = self.packed_weights_ws()
             check(self.lib.marl_episode_backward(
                 C.byref(cfg), wws.data_ptr(), _nbytes(wws), ws.data_ptr(), _nbytes(ws), img.data_ptr(), _ptr(gp),
                 _ptr(gl), _ptr(gv), self._table(grads), _stream(self.device)))
@@ -382,7 +400,7 @@ class HipEngine:
         gp = None if g_preds is None else _need(g_preds, th.float32, "g_preds")
         gl = None if g_logp is None else _need(g_logp, th.float32, "g_logp")
         gv = None if g_values is None else _need(g_values, th.float32, "g_values")
-        wws, ews = self.weights_ws(), self.episode_ws(True)
+        wws, ews = self.packed_weights_ws(), self.episode_ws(True)
         check(self.lib.marl_episode_backward(
             C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             self._fwd_img.data_ptr(), _ptr(gp), _ptr(gl), _ptr(gv), self._table(grads),
@@ -454,7 +472,7 @@ class HipEngine:
             lp = th.empty(na, nb, device=dev)
             extra = (act, lp)
         seed, offset = rng if rng is not None else (0, 0)
-        wws, ews = self.weights_ws(), self.episode_ws(False)
+        wws, ews = self.packed_weights_ws(), self.episode_ws(False)
         check(self.lib.marl_step_forward(
             C.byref(cfg), wws.data_ptr(), _nbytes(wws), ews.data_ptr(), _nbytes(ews),
             *[t.data_ptr() for t in ins], *[t.data_ptr() for t in outs], _ptr(nz), seed & _U64,

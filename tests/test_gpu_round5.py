@@ -23,6 +23,8 @@ DISTINCT = {
     "c3_resisc_b256": (C3_CFG, 16, 16, 16, (3, 256, 256), 16),   # BASELINE configs[2] as benched: R = 4096
     "c4_aid_b32": (C4_CFG, 16, 8, 16, (3, 600, 600), 4),        # configs[3] at 32 images per GPU: R = 512
     "c5_synth_b32": (C5_CFG, 64, 4, 32, (3, 1024, 1024), 8),   # configs[4] at 32 per GPU: R = 2048, 64 agents
+    # round 6: configs[3]'s weak-scaling variant, 256 images per GPU: R = 4096, AidCnn, stride 3
+    "c4_aid_b256": (C4_CFG, 16, 8, 16, (3, 600, 600), 32),
 }
 
 
