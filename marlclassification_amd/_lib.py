@@ -17,7 +17,9 @@ MARL_ABI_VERSION = 3
 MARL_COUNTERS_BYTES = 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmarl_hip.so")
+# MARL_LIB_PATH: another build of the SAME library (tools/build_variant.sh: timing / ablation builds, the previous
+# round's library for same-box A/Bs) - never a different implementation: load() checks the ABI and every export
+LIB_PATH = os.environ.get("MARL_LIB_PATH") or os.path.join(_HERE, "csrc", "libmarl_hip.so")
 
 
 class MarlConfig(C.Structure):

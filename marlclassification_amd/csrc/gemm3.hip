@@ -490,6 +490,384 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
 }
 
 // ---------------------------------------------------------------------------
+// Phase-pipelined NT / fused LSTM cell (round 6).  Same operands, same six products in the same order and the same
+// epilogue arithmetic as gemm_nt3_kernel - bit-identical results - on ONE 256-row workgroup per CU whose K step is
+// cut into phases (one per 32-row block of A, the wider side of the wave tile): the fragments of phase ph + 1 and of
+// step s + 1 are read, and the LDS-DMA pieces of step s + NST - 1 are issued, BETWEEN the MFMAs of the phase before
+// they are needed, so a wave's matrix chain only breaks at the two barriers of a step (B0 at the step boundary:
+// slot s - 1 is free; B1 mid step: the DMA of step s + 1 has landed).  Measured on the row-contraction twin of this
+// loop with memory out of the way (32 workgroups, tools/tn_pipe_probe.py): 100.5 us against 98 us for MFMAs and
+// barriers alone (round 5's loop: 142 us).  LDS-DMA is issued by inline asm (dma16): the order inside the pinned
+// phase is fixed with sched_barrier(0) - an asm statement has no scheduling class.
+// LSTM: tile = 4 gates x 32 units, WN = 2: wave (wm, wn) holds gates 2 wn, 2 wn + 1 of its rows; the gates meet in
+// LDS panels for the cell update (the arithmetic of the one-wave form, element by element).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NST, bool LSTM>
+__global__ __launch_bounds__(WM* WN * 64, 1) void gemm_nt3p_kernel(const G3Batch batch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NP = TM, NIN = TN;  // phases walk the A blocks; B's fragments stay for the step
+    static_assert(TM >= TN && (NP == 2 || NP == 4) && NST >= 3, "phase pipeline: 2 or 4 A blocks per wave, >= 3 stages");
+    static_assert(!LSTM || (BN == 128 && WN * TN == 4), "LSTM tile = 4 gates x 32 units");
+    constexpr int A_BYTES = BM * kImgRowBytes, B_BYTES = BN * kImgRowBytes, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INS = A_BYTES / 1024, B_INS = B_BYTES / 1024;
+    static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0 && A_INS % NW == 0, "whole LDS-DMA instructions, A's first");
+    constexpr int T_INS = A_INS + B_INS, NI_LO = T_INS / NW, NI_HI = (T_INS + NW - 1) / NW;
+    constexpr int I_EXTRA = T_INS % NW;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (batch.xcd_map) xcd_tile(batch.gx, batch.gy, batch.count, bx, by, bz);
+    const G3Prob& P = batch.p[bz];
+    const int M = P.m;
+    const int N = P.n;  // LSTM: hidden units (B has 4 N rows)
+    const int n0 = by * (LSTM ? 32 : BN);
+    const int m0 = bx * BM;
+    if (m0 >= M || n0 >= N) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool extra_i = wave < I_EXTRA;
+    const int S0 = P.seg[0].steps, S = S0 + (P.nseg > 1 ? P.seg[1].steps : 0);
+    int safe_i = batch.safe;
+    asm volatile("" : "+s"(safe_i));
+    const bool safe = safe_i == 1;
+
+    // ---- LDS-DMA source offsets (as gemm_nt3_kernel): instruction t = wave + NW i covers pieces q = 64 t' + lane
+    int voff[NI_HI];
+    i32x4 rA, rB;
+    auto set_seg = [&](int sg) {
+        const G3Seg& g = P.seg[sg];
+        const int blk = g.steps * kImgChunkBytes;
+        const int64_t a_first = (int64_t)g.a_row0 + m0;
+        const int a_blk0 = (int)(a_first >> 5);
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) {
+            const int t = wave + NW * i;
+            const bool isA = i < A_INS / NW;
+            const int q = (isA ? t : t - A_INS) * 64 + lane;
+            int row = q / 6;
+            const int w = q - row * 6;
+            const int sw = (row >> 3) & 1;
+            int grow;
+            if (isA) {
+                row = m0 + row < M ? row : M - 1 - m0;
+                grow = (int)(a_first + row - ((int64_t)a_blk0 << 5));
+            } else if (LSTM) {
+                int unit = n0 + (row & 31);
+                unit = unit < N ? unit : N - 1;
+                grow = g.b_row0 + (row >> 5) * N + unit;
+            } else {
+                grow = n0 + row;
+                grow = g.b_row0 + (grow < N ? grow : N - 1);
+            }
+            voff[i] = (grow >> 5) * blk + (grow & 31) * kImgRowBytes + (w >> 1) * 32 + (((w & 1) ^ sw) << 4);
+        }
+        rA = dma_rsrc(g.a3 + (size_t)a_blk0 * blk);
+        rB = dma_rsrc(g.b3);
+    };
+    const unsigned sm_lds = (unsigned)reinterpret_cast<unsigned long long>((lds_ptr)sm);
+    int gi = 0, islot = 0;
+    auto issue_begin = [&]() {
+        if (gi == S0) set_seg(1);
+    };
+#ifdef MARL_G3_ABLATE
+    const bool nodma = batch.safe == 2, nomma = batch.safe == 3;  // perf diagnosis (wrong results)
+#endif
+    auto issue_one = [&](int i) {
+        if (i == NI_LO && !extra_i) return;
+#ifdef MARL_G3_ABLATE
+        if (nodma) return;
+#endif
+        dma16(i < A_INS / NW ? rA : rB, sm_lds + islot * ST_BYTES + (wave + NW * i) * 1024, voff[i],
+              (gi >= S0 ? gi - S0 : gi) * kImgChunkBytes);
+    };
+    auto issue_done = [&]() {
+        ++gi;
+        islot = islot + 1 == NST ? 0 : islot + 1;
+    };
+    auto issue = [&]() {
+        issue_begin();
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) issue_one(i);
+        issue_done();
+    };
+
+    const int fsw = ((lane >> 5) ^ ((lane >> 3) & 1)) << 4;
+    const char* lA = sm + (wm * (BM / WM) + (lane & 31)) * kImgRowBytes + fsw;
+    const char* lB = sm + A_BYTES + (wn * (BN / WN) + (lane & 31)) * kImgRowBytes + fsw;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 fi0[3][NIN], fi1[3][NIN], fo0[3], fo1[3];  // B of step s / s + 1; A block of phase ph / ph + 1
+#define NP_LOAD_IN(dst_, so_, p_lo_, p_hi_)                                                           \
+    _Pragma("unroll") for (int p = (p_lo_); p < (p_hi_); ++p)                                         \
+        _Pragma("unroll") for (int b = 0; b < NIN; ++b)                                                \
+            dst_[p][b] = *reinterpret_cast<const bf16x8*>(lB + (so_) + b * 32 * kImgRowBytes + p * 32);
+#define NP_LOAD_OUT1(dst_, so_, ob_, p_) dst_[p_] = *reinterpret_cast<const bf16x8*>(lA + (so_) + (ob_) * 32 * kImgRowBytes + (p_) * 32);
+#define NP_LOAD_OUT(dst_, so_, ob_) _Pragma("unroll") for (int p = 0; p < 3; ++p) NP_LOAD_OUT1(dst_, so_, ob_, p)
+#define NP_P(in_, out_, ob_, pa_, pb_)                                                                \
+    _Pragma("unroll") for (int b = 0; b < NIN; ++b)                                                   \
+        acc[ob_][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(out_[pa_], in_[pb_][b], acc[ob_][b], 0, 0, 0);
+#define NP_MMA(in_, out_, ob_)                                                                        \
+    NP_P(in_, out_, ob_, 1, 1) NP_P(in_, out_, ob_, 0, 2) NP_P(in_, out_, ob_, 2, 0)                  \
+    NP_P(in_, out_, ob_, 0, 1) NP_P(in_, out_, ob_, 1, 0) NP_P(in_, out_, ob_, 0, 0)
+#define NP_SCHED(nr_)                                                                                 \
+    {                                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < (nr_); ++q) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+        }                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NIN - (nr_), 0);                              \
+    }
+#define NP_WAIT(k_)                                                                                   \
+    if (I_EXTRA > 0 && extra_i) wait_vm<(k_) * NI_HI>(); else wait_vm<(k_) * NI_LO>();
+#define NP_PIN() __builtin_amdgcn_sched_barrier(0);
+    // pieces q, q + 6, ... of the step behind product q of the pinned phase
+#define NP_PIECES(q_)                                                                                 \
+    _Pragma("unroll") for (int i = (q_); i < NI_HI; i += 6) issue_one(i);
+#define NP_PHASE0_PINNED(ina_)                                                                        \
+    {                                                                                                 \
+        issue_begin();                                                                                \
+        NP_P(ina_, fo0, 0, 1, 1) NP_PIN() NP_PIECES(0) NP_LOAD_OUT1(fo1, so, 1, 0) NP_PIN()           \
+        NP_P(ina_, fo0, 0, 0, 2) NP_PIN() NP_PIECES(1) NP_PIN()                                       \
+        NP_P(ina_, fo0, 0, 2, 0) NP_PIN() NP_PIECES(2) NP_LOAD_OUT1(fo1, so, 1, 1) NP_PIN()           \
+        NP_P(ina_, fo0, 0, 0, 1) NP_PIN() NP_PIECES(3) NP_PIN()                                       \
+        NP_P(ina_, fo0, 0, 1, 0) NP_PIN() NP_PIECES(4) NP_LOAD_OUT1(fo1, so, 1, 2) NP_PIN()           \
+        NP_P(ina_, fo0, 0, 0, 0) NP_PIN() NP_PIECES(5) NP_PIN()                                       \
+        issue_done();                                                                                 \
+    }
+#define NP_PHASE(ina_, inb_, ph_, MAIN_)                                                              \
+    {                                                                                                 \
+        constexpr int ph = (ph_);                                                                     \
+        constexpr bool second = ph >= NP / 2, last = ph == NP - 1;                                    \
+        constexpr int h2 = NP / 2, pl = (NP == 2 || ph == h2) ? 0 : 2, phi = NP == 2 ? 3 : (ph == h2 ? 2 : 3); \
+        const bool nxt = MAIN_ || s + 1 < S;                                                          \
+        if constexpr (!last) {                                                                        \
+            if constexpr (ph & 1) { NP_LOAD_OUT(fo0, so, ph + 1) } else { NP_LOAD_OUT(fo1, so, ph + 1) } \
+        } else if (nxt) { NP_LOAD_OUT(fo0, sn, 0) }                                                   \
+        if constexpr (second) { if (nxt) { NP_LOAD_IN(inb_, sn, pl, phi) } }                          \
+        if constexpr (ph & 1) { NP_MMA(ina_, fo1, ph) } else { NP_MMA(ina_, fo0, ph) }                \
+        if (MAIN_) NP_SCHED(3 + (second ? NIN * (phi - pl) : 0))                                      \
+    }
+#define NP_BODY(ina_, inb_, MAIN_)                                                                    \
+    {                                                                                                 \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                           \
+        __builtin_amdgcn_s_barrier(); /* B0 */                                                        \
+        const int rn = rs + 1 == NST ? 0 : rs + 1;                                                    \
+        const int so = rs * ST_BYTES, sn = rn * ST_BYTES;                                             \
+        if (MAIN_) { NP_PHASE0_PINNED(ina_) }                                                         \
+        else {                                                                                        \
+            if (gi < S) issue();                                                                      \
+            NP_PHASE(ina_, inb_, 0, MAIN_)                                                            \
+        }                                                                                             \
+        if constexpr (NP == 4) NP_PHASE(ina_, inb_, 1, MAIN_)                                         \
+        if (MAIN_ && !safe) { NP_WAIT(NST - 2) } else wait_vm<0>();                                   \
+        __builtin_amdgcn_s_barrier(); /* B1 */                                                        \
+        if constexpr (NP == 4) { NP_PHASE(ina_, inb_, 2, MAIN_) NP_PHASE(ina_, inb_, 3, MAIN_) }      \
+        else NP_PHASE(ina_, inb_, 1, MAIN_)                                                           \
+        rs = rn;                                                                                      \
+        ++s;                                                                                          \
+    }
+    set_seg(0);
+    {
+#pragma unroll
+        for (int g = 0; g < NST - 1; ++g)
+            if (g < S) issue();
+        if (!safe && S >= NST - 1) { NP_WAIT(NST - 2) } else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        int s = 0, rs = 0;
+        NP_LOAD_IN(fi0, 0, 0, 3)
+        NP_LOAD_OUT(fo0, 0, 0)
+        while (gi + 1 < S) {
+            NP_BODY(fi0, fi1, true)
+            NP_BODY(fi1, fi0, true)
+        }
+        while (s + 1 < S) {
+            NP_BODY(fi0, fi1, false)
+            NP_BODY(fi1, fi0, false)
+        }
+        if (s < S) NP_BODY(fi0, fi1, false)
+    }
+#undef NP_BODY
+#undef NP_PHASE
+#undef NP_PHASE0_PINNED
+#undef NP_PIECES
+#undef NP_PIN
+#undef NP_WAIT
+#undef NP_SCHED
+#undef NP_MMA
+#undef NP_P
+#undef NP_LOAD_OUT
+#undef NP_LOAD_OUT1
+#undef NP_LOAD_IN
+
+    // ---- epilogue (wave-private LDS panels, 16-byte stores: see gemm_nt3_kernel)
+    constexpr int HLD = 36;
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    float* hp = reinterpret_cast<float*>(sm) + wave * 32 * HLD;
+    const int tr = lane >> 3, tc = (lane & 7) * 4;
+    __syncthreads();
+    if constexpr (!LSTM) {
+        const bool vec = (P.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(P.c) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cb = n0 + wn * (BN / WN) + j * 32;
+                if (cb >= N) continue;
+                const int rb = m0 + wm * (BM / WM) + i * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hp[((r & 3) + 8 * (r >> 2) + row_h) * HLD + col_l] = acc[i][j][r];
+                wait_lgkm0();
+                const int col = cb + tc;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P.bias) {
+                    bv.x = col < N ? P.bias[col] : 0.f;
+                    bv.y = col + 1 < N ? P.bias[col + 1] : 0.f;
+                    bv.z = col + 2 < N ? P.bias[col + 2] : 0.f;
+                    bv.w = col + 3 < N ? P.bias[col + 3] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rb + tr + 8 * q;
+                    float4 v = *reinterpret_cast<const float4*>(hp + (tr + 8 * q) * HLD + tc);
+                    v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    if (row >= M || col >= N) continue;
+                    float* cp = P.c + (size_t)row * P.ldc + col;
+                    if (vec && col + 3 < N) {
+                        if (P.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(cp);
+                            v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(cp) = v;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (col + u < N) cp[u] = P.accumulate ? cp[u] + e[u] : e[u];
+                    }
+                }
+                wait_lgkm0();
+            }
+    } else {
+        // ---- gates meet in LDS: per 32-row block i of the wave tiles, panel (wm, gate) <- activated gate; then the
+        // WN x 64 threads of row group wm share the block's 32 x 32 (row, unit) elements, eight consecutive units each
+        static_assert(WN == 2 && TN == 2, "LSTM epilogue: two gates per wave");
+        constexpr int PANEL = 32 * HLD;                                // floats
+        float* gpan = reinterpret_cast<float*>(sm) + wm * 5 * PANEL;   // 4 gate panels + the h' panel of this row group
+        static_assert((size_t)WM * 5 * PANEL * 4 <= (size_t)NST * ST_BYTES, "gate panels fit the ring");
+        const int unit = n0 + col_l;
+        const int uc = unit < N ? unit : N - 1;
+        const float bg0 = P.bias[(2 * wn) * N + uc], bg1 = P.bias[(2 * wn + 1) * N + uc];
+        const int t = wn * 64 + lane, er = t >> 2, ec = (t & 3) * 8;  // this thread's element group in the block
+        const bool svec = (P.ld_state & 3) == 0;
+        const bool gvec = (N & 3) == 0 && (P.ld_gates & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i > 0) __syncthreads();  // the panels of block i - 1 have been read
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = 2 * wn + j;
+                const float bg_ = j ? bg1 : bg0;
+                float* pp = gpan + g * PANEL;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[i][j][r] + bg_;
+                    pp[((r & 3) + 8 * (r >> 2) + row_h) * HLD + col_l] = g == 2 ? tanh_fast(x) : sigmoid_acc(x);
+                }
+            }
+            __syncthreads();
+            const int row = m0 + wm * (BM / WM) + i * 32 + er;
+            const bool rok = row < M;
+            const int rowc = rok ? row : M - 1;
+            float* hpn = gpan + 4 * PANEL;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {  // two groups of four consecutive units
+                const int ecq = ec + 4 * hq, col = n0 + ecq;
+                const float* gpn = gpan + er * HLD + ecq;
+                const float4 vi = *reinterpret_cast<const float4*>(gpn), vf = *reinterpret_cast<const float4*>(gpn + PANEL),
+                             vg = *reinterpret_cast<const float4*>(gpn + 2 * PANEL), vo = *reinterpret_cast<const float4*>(gpn + 3 * PANEL);
+                const bool col_ok = col < ((N + 3) & ~3);
+                float cp[4];
+                if (svec && col_ok) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(P.c_prev + (size_t)rowc * P.ld_state + col);
+                    cp[0] = c4.x, cp[1] = c4.y, cp[2] = c4.z, cp[3] = c4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cp[e] = P.c_prev[(size_t)rowc * P.ld_state + (col + e < N ? col + e : N - 1)];
+                }
+                const float gi4[4] = {vi.x, vi.y, vi.z, vi.w}, gf4[4] = {vf.x, vf.y, vf.z, vf.w},
+                            gg4[4] = {vg.x, vg.y, vg.z, vg.w}, go4[4] = {vo.x, vo.y, vo.z, vo.w};
+                float cn[4], hn[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool uok = col + e < N;
+                    const float c_ = gf4[e] * cp[e] + gi4[e] * gg4[e];
+                    cn[e] = uok ? c_ : 0.f;
+                    hn[e] = uok ? go4[e] * tanh_fast(c_) : 0.f;
+                }
+                *reinterpret_cast<float4*>(hpn + er * HLD + ecq) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                if (rok) {
+                    float* cdst = P.c_next + (size_t)row * P.ld_state + col;
+                    float* hdst = P.h_next + (size_t)row * P.ld_state + col;
+                    if (svec) {
+                        if (col_ok) {
+                            *reinterpret_cast<float4*>(cdst) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+                            *reinterpret_cast<float4*>(hdst) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < N) cdst[e] = cn[e], hdst[e] = hn[e];
+                    }
+                    if (P.gates) {
+                        float* gd = P.gates + (size_t)row * P.ld_gates + col;
+                        if (gvec) {
+                            if (col_ok) {
+                                *reinterpret_cast<float4*>(gd) = vi;
+                                *reinterpret_cast<float4*>(gd + N) = vf;
+                                *reinterpret_cast<float4*>(gd + 2 * N) = vg;
+                                *reinterpret_cast<float4*>(gd + 3 * N) = vo;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col + e < N) gd[e] = gi4[e], gd[N + e] = gf4[e], gd[2 * N + e] = gg4[e], gd[3 * N + e] = go4[e];
+                        }
+                    }
+                }
+            }
+            if (P.h3) {
+                __syncthreads();
+                if (wn == 0) {  // one image step of one row per lane: 96 contiguous bytes
+                    const int lr = lane >> 1, u0 = (lane & 1) * 16;
+                    const int irow = m0 + wm * (BM / WM) + i * 32 + lr;
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(hpn + lr * HLD + u0 + 4 * q);
+                        v[4 * q] = t4.x, v[4 * q + 1] = t4.y, v[4 * q + 2] = t4.z, v[4 * q + 3] = t4.w;
+                    }
+                    if (irow < M && n0 + u0 < ((N + 15) & ~15))
+                        img_store16(P.h3 + img_off((int64_t)P.h3_row0 + irow, (n0 + u0) >> 4, P.h3_steps), v);
+                }
+            }
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // TN: C[NI,NJ] = sum_r A[r,i] * B[r,j] over the row slab of this workgroup (weight gradients), both
 // operands k16 images whose ROWS are the contraction index.  A stage = 16 rows x (BI + BJ) columns:
 // per 16-column step of an operand 1536 contiguous bytes (half a row block), so the LDS stage is
@@ -503,6 +881,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_nt3_kernel(const G3Batch 
 // ---------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
+#ifndef MARL_TN_PIN
+#define MARL_TN_PIN 1
+#endif
+[[maybe_unused]] constexpr bool kTnPin = MARL_TN_PIN != 0;  // pipelined loop: LDS-DMA pieces pinned between the MFMAs of phase 0
 
 // DB: fragments double-buffered in registers (step s + 1 read while step s multiplies, NST - 2 steps in
 // flight); !DB (the 256 x 256 tile: 128 accumulator registers leave room for one fragment set): the
@@ -554,19 +936,26 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
     // same operand (no per-instruction branch on the resource)
     constexpr bool A_STATIC = A_INS % NW == 0;
     int gi = 0, islot = 0;
-    auto issue = [&]() {
+    // instruction i of step gi (the pinned phase of the pipelined loop places them one by one between MFMAs)
+    auto issue_one = [&](int i) {
+        if (i == NI_LO && !extra_i) return;
         const int half = (gi & 1) * CS_BYTES;  // rows 0..15 / 16..31 of the row block gi / 2
-        const int soffA = (gi >> 1) * a_blk + half, soffB = (gi >> 1) * b_blk + half;
-        const unsigned base = sm_lds + islot * ST_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < NI_HI; ++i) {
-            if (i == NI_LO && !extra_i) break;
-            const bool isA = A_STATIC ? i < A_INS / NW : wave + NW * i < A_INS;
-            dma16(isA ? rA : rB, base + NW * i * 1024, voff[i], isA ? soffA : soffB);
-        }
+        const bool isA = A_STATIC ? i < A_INS / NW : wave + NW * i < A_INS;
+        dma16(isA ? rA : rB, sm_lds + islot * ST_BYTES + (wave + NW * i) * 1024, voff[i],
+              (gi >> 1) * (isA ? a_blk : b_blk) + half);
+    };
+    auto issue_done = [&]() {
         ++gi;
         islot = islot + 1 == NST ? 0 : islot + 1;
     };
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI_HI; ++i) issue_one(i);
+        issue_done();
+    };
+    int safe_i = P.safe;  // (pinned in a scalar register: hipcc re-loaded the kernel argument inside the K loop,
+    asm volatile("" : "+s"(safe_i));  //  and its s_waitcnt lgkmcnt(0) also waited for the LDS reads in flight)
+    const bool safe = safe_i != 0;
 
     // fragment addresses (see the header): 16-lane group g = lane / 16 -> column sub-step g & 1, row
     // group g / 2; lane j = 4 q + piece; the two reads of a fragment take rows 4 h + q, h = 0, 1
@@ -624,7 +1013,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
     if (I_EXTRA > 0 && extra_i) wait_vm<(k_) * NI_HI>(); else wait_vm<(k_) * NI_LO>();
 #define G3T_BODY(fa_, fb_, fan_, fbn_, MAIN_)                                                        \
     {                                                                                                \
-        if (MAIN_ && !P.safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                               \
+        if (MAIN_ && !safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                               \
         __builtin_amdgcn_s_waitcnt(0xc07f);                                                          \
         __builtin_amdgcn_s_barrier();                                                                \
         if (MAIN_ || gi < S) issue();                                                                \
@@ -714,16 +1103,41 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
             }                                                                                         \
             if (MAIN_) TP_SCHED(6 + (second ? 2 * NIN * (phi - pl) : 0), ph == 0 ? NI_HI : 0, CS && ph == 0 ? 3 * TM : 0) \
         }
+        // phase 0 of a main-loop step, hand-ordered: the six products of the phase (NIN MFMAs each) with ONE LDS-DMA
+        // piece of step s + NST - 1 behind each of the first NI_HI and one fragment of outer block 1 behind every
+        // second - an asm-issued DMA has no scheduling class, so sched_barrier(0) pins the order (the pieces cost
+        // 60-185 cycles of issue each, MI355X_MICROARCH.md: behind a barrier, all waves at once, they idled the pipe)
+#define TP_PIN() __builtin_amdgcn_sched_barrier(0);
+#define TP_PHASE0_PINNED(ina_)                                                                        \
+        {                                                                                             \
+            TP_P(ina_, fo0, 0, 1, 1) TP_PIN() issue_one(0); fo1[0] = G3T_FRAG(lO0, lO1, so + 2 * CS_BYTES); TP_PIN() \
+            TP_P(ina_, fo0, 0, 0, 2) TP_PIN() issue_one(1); TP_PIN()                                  \
+            TP_P(ina_, fo0, 0, 2, 0) TP_PIN() issue_one(2); fo1[1] = G3T_FRAG(lO0, lO1, so + 2 * CS_BYTES + 32); TP_PIN() \
+            TP_P(ina_, fo0, 0, 0, 1) TP_PIN() issue_one(3); TP_PIN()                                  \
+            TP_P(ina_, fo0, 0, 1, 0) TP_PIN() if constexpr (NI_HI > 4) issue_one(4); fo1[2] = G3T_FRAG(lO0, lO1, so + 2 * CS_BYTES + 64); TP_PIN() \
+            TP_P(ina_, fo0, 0, 0, 0) TP_PIN() if constexpr (NI_HI > 5) issue_one(5); TP_PIN()        \
+            _Pragma("unroll") for (int i = 6; i < NI_HI; ++i) issue_one(i);                           \
+            issue_done();                                                                             \
+            if constexpr (CS) {                                                                       \
+                _Pragma("unroll") for (int p = 2; p >= 0; --p)                                        \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                    \
+                        accs[CS ? i : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ina_[p][CS ? i : 0], ones, accs[CS ? i : 0], 0, 0, 0); \
+            }                                                                                         \
+            TP_PIN()                                                                                  \
+        }
 #define TP_BODY(ina_, inb_, MAIN_)                                                                    \
         {                                                                                             \
             __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): my reads of slot s - 1 (and of step s's first fragments) */ \
             __builtin_amdgcn_s_barrier();       /* B0 */                                              \
             const int rn = rs + 1 == NST ? 0 : rs + 1;                                                \
             const int so = rs * ST_BYTES, sn = rn * ST_BYTES;                                         \
-            if (MAIN_ || gi < S) issue();                                                             \
-            TP_PHASE(ina_, inb_, 0, MAIN_)                                                            \
+            if (MAIN_ && kTnPin) { TP_PHASE0_PINNED(ina_) }                                           \
+            else {                                                                                    \
+                if (MAIN_ || gi < S) issue();                                                         \
+                TP_PHASE(ina_, inb_, 0, MAIN_)                                                        \
+            }                                                                                         \
             if constexpr (NP == 4) TP_PHASE(ina_, inb_, 1, MAIN_)                                     \
-            if (MAIN_ && !P.safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                            \
+            if (MAIN_ && !safe) { G3T_WAIT(NST - 2) } else wait_vm<0>();                            \
             __builtin_amdgcn_s_barrier();       /* B1 */                                              \
             if constexpr (NP == 4) { TP_PHASE(ina_, inb_, 2, MAIN_) TP_PHASE(ina_, inb_, 3, MAIN_) }  \
             else TP_PHASE(ina_, inb_, 1, MAIN_)                                                       \
@@ -735,7 +1149,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #pragma unroll
             for (int g = 0; g < NST - 1; ++g)
                 if (g < S) issue();
-            if (!P.safe && S >= NST - 1) { G3T_WAIT(NST - 2) } else wait_vm<0>();
+            if (!safe && S >= NST - 1) { G3T_WAIT(NST - 2) } else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             int s = 0, rs = 0;
             TP_LOAD_IN(fi0, 0, 0, 3)
@@ -751,6 +1165,8 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
             if (s < S) TP_BODY(fi0, fi1, false)
         }
 #undef TP_BODY
+#undef TP_PHASE0_PINNED
+#undef TP_PIN
 #undef TP_PHASE
 #undef TP_SCHED
 #undef TP_MMA
@@ -762,7 +1178,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
 #pragma unroll
         for (int g = 0; g < NST; ++g)
             if (g < S) issue();
-        if (!P.safe && S >= NST) { G3T_WAIT(NST - 1) } else wait_vm<0>();
+        if (!safe && S >= NST) { G3T_WAIT(NST - 1) } else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         int s = 0, rslot = 0;
         G3T_LOADF(fa0, fb0, 0)
@@ -785,7 +1201,7 @@ __device__ __forceinline__ void gemm_tn3_body(const G3TnArgs& P, char* sm, unsig
         // fragment reads, 4 neither DMA nor fragment reads
         if (ABL == 3 || ABL == 4) G3T_LOADF(fa0, fb0, 0)
         for (int s = 0; s < S; ++s) {
-            if (!P.safe && gi < S) { G3T_WAIT(NST - 2) } else wait_vm<0>();
+            if (!safe && gi < S) { G3T_WAIT(NST - 2) } else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             if (ABL == 1 || ABL == 4) { if (gi < S) ++gi; } else if (gi < S) issue();
             if (ABL != 3 && ABL != 4) G3T_LOADF(fa0, fb0, rslot)
@@ -1012,7 +1428,12 @@ static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st
     batch.gy = (int)grid.y;
     // XCD-contiguous tile order: single products always; the two-cell LSTM launch by knob (each half of the XCDs then
     // streams ONE cell's 3.8 MB of weight images - they fit its L2 - at the price of fetching A's row tiles twice)
-    batch.xcd_map = tune_get("nt_xcd", 1) && (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1);
+    // (round 6: also several products of ONE shape - the two batched heads: their three 128-column tiles per row tile
+    // were spread over the XCDs and A left HBM three times; knob nt_xcd_multi)
+    bool same = true;
+    for (int i = 1; i < batch.count; ++i) same = same && batch.p[i].m == batch.p[0].m && batch.p[i].n == batch.p[0].n;
+    batch.xcd_map = tune_get("nt_xcd", 1) &&
+                    (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1 || (same && tune_get("nt_xcd_multi", 1) != 0));
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     batch.safe = tune_get("g3_safe", 0);
     constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
@@ -1055,6 +1476,34 @@ static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st
                 (double)(h[2] - h[0]) / ((h[3] - h[1]) * 0.01));
     }
 #endif
+    MARL_LAUNCH_CHECK();
+    return MARL_OK;
+}
+
+// the phase-pipelined kernels (gemm_nt3p_kernel): one 256-row workgroup per CU
+template <int BM, int BN, int WM, int WN, int NST, bool LSTM>
+static int launch_g3p_variant(G3Batch batch, int max_m, int max_n, hipStream_t st) {
+    dim3 grid((unsigned)cdiv(max_m, BM), (unsigned)cdiv(max_n, LSTM ? 32 : BN), (unsigned)batch.count);
+    batch.gx = (int)grid.x;
+    batch.gy = (int)grid.y;
+    bool same = true;
+    for (int i = 1; i < batch.count; ++i) same = same && batch.p[i].m == batch.p[0].m && batch.p[i].n == batch.p[0].n;
+    batch.xcd_map = tune_get("nt_xcd", 1) && (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1 || same);
+    if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
+    batch.safe = tune_get("g3_safe", 0);
+#ifndef MARL_G3_ABLATE
+    batch.safe = batch.safe != 0;
+#endif
+    constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
+    static_assert(lds <= 160 * 1024, "LDS ring");
+    static_assert((size_t)WM * WN * 32 * 36 * 4 <= lds, "epilogue panels fit the ring");
+    auto kern = gemm_nt3p_kernel<BM, BN, WM, WN, NST, LSTM>;
+    static bool raised = false;
+    if (!raised) {
+        MARL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, batch);
     MARL_LAUNCH_CHECK();
     return MARL_OK;
 }
@@ -1104,6 +1553,10 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
         const int v_big = tune_get("g3_nt_v_big", 2), v_mid = tune_get("g3_nt_v_mid", 2),
                   v_small = tune_get("g3_nt_v_small", 7);
         variant = max_n < 96 ? v_small : blocks128 >= 1024 ? v_big : blocks128 >= tune_get("g3_nt_mid_blocks", 256) ? v_mid : v_small;
+        // round 6: ONE long product whose width is a whole number of 256-column tiles (dU: [Ns R x 256] over both cells'
+        // gate gradients) -> the phase-pipelined 256 x 256 plan: A is read once instead of once per 128-column tile
+        // (lab 182 -> 165 us on [65536 x 256 x 1024]; iteration -0.02 ms; the heads, n = 384, keep 128 x 128: 88 vs 78 us)
+        if (variant == 2 && blocks128 >= 1024 && batch.count == 1 && max_n % 256 == 0 && tune_get("g3_nt_p256", 1) != 0) variant = 21;
     }
     prof_before(1, st);
     int rc;
@@ -1125,6 +1578,10 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
         rc = launch_g3_variant<128, 64, 4, 2, 3, false>(batch, max_m, max_n, st);
     else if (variant == 12)
         rc = launch_g3_variant<64, 64, 2, 2, 3, false>(batch, max_m, max_n, st);
+    else if (variant == 21)  // phase-pipelined, 256 x 256 / 8 waves (round 6)
+        rc = launch_g3p_variant<256, 256, 2, 4, 3, false>(batch, max_m, max_n, st);
+    else if (variant == 22)  // phase-pipelined, 256 x 128 / 8 waves
+        rc = launch_g3p_variant<256, 128, 4, 2, 4, false>(batch, max_m, max_n, st);
 
     else
         rc = launch_g3_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
@@ -1167,6 +1624,10 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
         rc = launch_g3_variant<32, 128, 1, 4, 4, true>(batch, max_m, max_n, st);
     else if (variant == 4)
         rc = launch_g3_variant<64, 128, 2, 4, 4, true>(batch, max_m, max_n, st);
+    else if (variant == 5)  // phase-pipelined 256-row tiles (round 6): eight waves of 64 x 64 ...
+        rc = launch_g3p_variant<256, 128, 4, 2, 4, true>(batch, max_m, max_n, st);
+    else if (variant == 6)  // ... or four waves of 128 x 64 (one per SIMD)
+        rc = launch_g3p_variant<256, 128, 2, 2, 4, true>(batch, max_m, max_n, st);
     else
         rc = launch_g3_variant<128, 128, 4, 1, 3, true>(batch, max_m, max_n, st);
     prof_after(0, st);

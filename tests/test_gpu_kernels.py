@@ -233,7 +233,8 @@ def _image(lib, check, device, t, k):
                                    # the shapes of tools/g3_lab.py (a stale lab record showed wrong
                                    # results on exactly these, under forced variants, and no test covered them)
                                    (4096, 256, 1024), (65536, 384, 256), (4096, 1024, 624)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 7, 11, 12], ids=["256x128", "128x128", "128x64", "64x64", "128x64w8", "64x64s3"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7, 11, 12, 21, 22],
+                         ids=["256x128", "128x128", "128x64", "64x64", "128x64w8", "64x64s3", "256x256_pipelined", "256x128_pipelined"])
 @pytest.mark.parametrize("acc", [0, 1])
 def test_gemm_nt_images(device, m, n, k, variant, acc):
     lib, check = _lib()
@@ -271,14 +272,15 @@ def test_gemm_nt_images_six_products_kat(device):
     a, b, want = _kat_operands(m, n, k)
     a3 = _image(lib, check, device, a.to(device), k)
     b3 = _image(lib, check, device, b.to(device), k)
-    for variant in (1, 2, 3, 7, 11, 12):
+    for variant in (1, 2, 3, 7, 11, 12, 21, 22):
         cd = th.zeros(m, n, device=device)
         check(lib.marl_gemm_nt_images(a3.data_ptr(), b3.data_ptr(), None, cd.data_ptr(), n, m, n, k, 0, variant, None))
         assert th.equal(cd.cpu().double(), want)
 
 
 @pytest.mark.parametrize("m,n,nin", [(4096, 256, 368), (777, 23, 45), (96, 64, 96), (300, 80, 200), (512, 256, 624)])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["256rows", "128rows", "32rows_gate_split", "64rows_gate_split"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6], ids=["256rows", "128rows", "32rows_gate_split", "64rows_gate_split",
+                                                              "256rows_pipelined_8waves", "256rows_pipelined_4waves"])
 def test_lstm_images(device, m, n, nin, variant):
     """fused cell (networks/recurrent.py:19-35) from images against float64, and the image of h' it writes
     against the image of the h' it wrote in fp32"""
@@ -309,7 +311,7 @@ def test_lstm_images(device, m, n, nin, variant):
     assert th.equal(_image(lib, check, device, hn, n)[:nb], h3n[:nb])
 
 
-@pytest.mark.parametrize("m,n,nin", [(512, 256, 624), (2048, 256, 624), (333, 100, 77)])
+@pytest.mark.parametrize("m,n,nin", [(512, 256, 624), (2048, 256, 624), (333, 100, 77), (4096, 256, 368)])
 def test_lstm_gate_split_equals_the_one_wave_form(device, m, n, nin):
     """the small-batch plans (one gate per wave, 32- / 64-row tiles: BASELINE configs[3], [4] at 32 images per GPU)
     run the same K loop and the same cell arithmetic as the 128-row kernel: h', c', the activated gates and the
@@ -323,7 +325,7 @@ def test_lstm_gate_split_equals_the_one_wave_form(device, m, n, nin):
     u3, h3, wih3, whh3 = img(u, nin), img(h, n), img(wih, nin), img(whh, n)
     cpd, bd = _padded(cprev.to(device), _p4(n)), bias.to(device)
     res = {}
-    for variant in (2, 3, 4):
+    for variant in (2, 3, 4, 5, 6):
         hn, cn = th.zeros(m, _p4(n), device=device), th.zeros(m, _p4(n), device=device)
         gt = th.zeros(m, _p4(4 * n), device=device)
         h3n = th.zeros(lib.marl_image_bytes(m, n) + 256, dtype=th.uint8, device=device)
@@ -331,7 +333,7 @@ def test_lstm_gate_split_equals_the_one_wave_form(device, m, n, nin):
                                    cpd.data_ptr(), hn.data_ptr(), cn.data_ptr(), gt.data_ptr(), h3n.data_ptr(), m, n,
                                    _p4(n), _p4(4 * n), variant, 1, None))
         res[variant] = (hn, cn, gt, h3n[: lib.marl_image_bytes(m, n)])
-    for variant in (3, 4):
+    for variant in (3, 4, 5, 6):  # (5, 6: the phase-pipelined 256-row kernels of round 6)
         for a, b, name in zip(res[2], res[variant], ("h", "c", "gates", "image")):
             assert th.equal(a, b), (variant, name)
 
