@@ -209,7 +209,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU (weak scaling); default: 256 for c3, the config's own otherwise (c4 / c5: 32; "
+                         "BASELINE configs[3]'s weak-scaling variant is --config c4 --batch 256)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many images in all, N / world per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,9 +227,11 @@ def main() -> None:
     workload = "RESISC45 256x256x3, 16 agents, 16 steps, f=12, README dims (configs[2])"
     if args.config != "c3":
         C3, NA, NS, IMG, default_batch, workload = OTHER[args.config]
-        if args.batch == 256:
+        if args.batch is None:
             args.batch = default_batch
         args.no_cpu_baseline = True
+    if args.batch is None:
+        args.batch = 256
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -252,7 +256,7 @@ def main() -> None:
     from marlclassification_amd.fused import FusedA2C, draw_episode, draw_episode_device
     from marlclassification_amd.networks import ModelsWrapper
     from marlclassification_amd.networks.vision import CNN_BY_NAME
-    from marlclassification_amd.parallel import GradAllReduce, broadcast_parameters, shard_seed
+    from marlclassification_amd.parallel import BucketedGradAllReduce, broadcast_parameters, shard_seed
 
     lib = _lib.load()
     actions = C3.get("actions", [[1, 0], [-1, 0], [0, 1], [0, -1]])
@@ -272,7 +276,7 @@ def main() -> None:
             raise SystemExit(f"--global-batch {args.global_batch} is not divisible by the world size {world}")
         nb = args.global_batch // world
     eng.configure(NA, nb, NS, IMG)
-    hook = GradAllReduce(world) if distributed else None
+    hook = BucketedGradAllReduce(world, None, flat.offsets, flat.numel, dev) if distributed else None
     fa = FusedA2C(eng, flat, LR, GAMMA, allreduce=hook, use_graph=args.graph)
 
     gen = th.Generator(device=dev).manual_seed(shard_seed(0, rank))
@@ -401,16 +405,16 @@ def main() -> None:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
         # THIS round (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), if they cover it
         # (only if they were taken from THIS library: the file carries the sha256 of csrc/*.hip|*.h)
-        tpath = os.path.join(ROOT, "profiles", "r05_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r06_traffic.json")
         if nb == 256 and is_c3 and not args.rollout_only and os.path.exists(tpath):
             with open(tpath, "r", encoding="utf-8") as f:
                 tj = json.load(f)
             ent = tj.get(str(dom))
             if ent and tj.get("src_sha256") == csrc_sha256():
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r05_traffic.json, sources match)"
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r06_traffic.json, sources match)"
             elif ent:
-                roofline["traffic_unit"] = ("null: profiles/r05_traffic.json was measured on other kernel "
+                roofline["traffic_unit"] = ("null: profiles/r06_traffic.json was measured on other kernel "
                                             "sources (sha256 differs)")
     if distributed:
         dist.barrier()

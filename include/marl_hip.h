@@ -198,6 +198,14 @@ int marl_episode_backward(const marl_config* cfg, void* weights_ws, size_t weigh
                           const void* img, const float* g_preds, const float* g_logp,
                           const float* g_values, float* const* grads_host, void* stream);
 
+/* Data-parallel overlap (no reference counterpart: training/trainer.py is single-device).  While an event
+ * is installed (per-process state, NULL clears it), every marl_episode_backward records it on its stream at the
+ * point where the gradients of the three heads' parameters (MARL_P_POL_* .. MARL_P_PRE_*: Policy / Critic /
+ * Prediction, networks/policy.py, prediction.py) are final - before the reverse-time loop and the batched weight
+ * gradients behind it.  The caller's side stream waits for it and all-reduces that slice of the flat gradient buffer
+ * while the rest of the backward pass runs (parallel.py, BucketedGradAllReduce). */
+int marl_backward_heads_event(void* hip_event);
+
 /* Loss of Trainer.train_epoch (training/trainer.py:76-111; training/functions.py:7-55)
  * and its gradient w.r.t. the episode outputs in one pass.
  * y int64 [Nb].  scalars_out[4] = {loss, path, error, critic} (trainer.py:111,119-122).

@@ -74,7 +74,7 @@ EXPORTS = (
     "marl_counters_set marl_counters_tick marl_graph_begin marl_graph_end marl_graph_launch "
     "marl_graph_destroy marl_image_bytes marl_image_build marl_gemm_nt_images marl_gemm_nt_images_batch "
     "marl_lstm_images marl_gemm_tn_images marl_gemm_tn_images_scratch marl_plan_query "
-    "marl_gemm_tn_images_cell marl_gemm_tn_images_cell_scratch"
+    "marl_gemm_tn_images_cell marl_gemm_tn_images_cell_scratch marl_backward_heads_event"
 ).split()
 
 _lib: Optional[C.CDLL] = None
@@ -141,6 +141,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.marl_gemm_tn_images_cell_scratch.argtypes = [_i, _i, _i, _i64]
     lib.marl_gemm_tn_images_cell.argtypes = [_vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]
     lib.marl_plan_query.argtypes = [_cfgp, _i, C.c_char_p, C.POINTER(_i)]
+    lib.marl_backward_heads_event.argtypes = [_vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("marl_abi_version", "marl_tune_get"):

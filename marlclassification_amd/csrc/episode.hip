@@ -1359,6 +1359,9 @@ static int gate_image_fallback(const Ctx& c, const PanelBwdProb& pd, int t) {
     return launch_images(ib, c.st);
 }
 
+// marl_backward_heads_event: recorded by episode_backward once the heads' parameter gradients are final
+static hipEvent_t g_heads_event = nullptr;
+
 static int episode_backward(const Ctx& c0, const void* img, int img_u8, const float* g_preds,
                             const float* g_logp, const float* g_values, float* const* grads) {
     Ctx c = c0;
@@ -1440,6 +1443,14 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
                                 c.DHCs(1), d.ld_na, (int)NR, d.n_a);
         gemm_add_seg(pa, c.at(c.e.DAC1), d.ld_nla, c.wt(MARL_P_CRI_W0), d.ld_nla, d.nla);
         MARL_TRY(gemm2(c, ph, pa));
+    }
+
+    // Data parallelism (parallel.py, BucketedGradAllReduce): every gradient of the three heads' parameters (POL_*,
+    // CRI_*, PRE_*) is complete here, ahead of the ~1.4 ms reverse loop - flush what they queued and mark the point.
+    if (hipEvent_t ev = g_heads_event) {
+        if (c.tq) MARL_TRY(launch_tn_queue(tq, c.rq, st));
+        MARL_TRY(rq.flush());
+        MARL_HIP_CHECK(hipEventRecord(ev, st));
     }
 
     // ---- reverse-time loop over the recurrent chain ----------------------------------
@@ -2063,6 +2074,11 @@ int marl_episode_backward(const marl_config* cfg, void* weights_ws, size_t weigh
         return MARL_EINVAL;
     }
     return episode_backward(c, img, cfg->img_u8 != 0, g_preds, g_logp, g_values, grads_host);
+}
+
+int marl_backward_heads_event(void* hip_event) {
+    g_heads_event = static_cast<hipEvent_t>(hip_event);
+    return MARL_OK;
 }
 
 int marl_draw_episode(const marl_config* cfg, uint64_t seed, uint64_t offset, const void* counters,

@@ -301,6 +301,11 @@ class HipEngine:
             arr[slot] = t.data_ptr()
         return arr
 
+    def set_heads_event(self, hip_event: Optional[int]) -> None:
+        """marl_backward_heads_event: the event episode_backward records once the heads' parameter gradients are
+        final (parallel.BucketedGradAllReduce); None clears it."""
+        check(self.lib.marl_backward_heads_event(hip_event))
+
     # -- calls ----------------------------------------------------------------------
     def pack(self, params: Dict[str, th.Tensor]) -> None:
         """marl_pack_weights: refresh the padded / transposed copies after an update."""

@@ -217,7 +217,14 @@ class FusedA2C:
                 th.zeros(3, dtype=th.float64, device=dev),
             )
         gp, gl, gv, scalars, _ = eng.a2c_loss(out, y, self.gamma, 0, self._loss_bufs)
-        eng.episode_backward(gp, gl, gv, self._gviews)
+        bucketed = hasattr(self.allreduce, "before_backward")
+        if bucketed:  # (two buckets: the heads' slice leaves while the reverse loop still runs)
+            self.allreduce.before_backward(eng)
+        try:
+            eng.episode_backward(gp, gl, gv, self._gviews)
+        finally:
+            if bucketed:
+                self.allreduce.after_backward(eng)
         scale = 1.0
         if self.allreduce is not None:
             scale = self.allreduce(self.flat.grads)

@@ -16,7 +16,7 @@ from torch.utils.data import DataLoader, Sampler
 from .config import MainConfig, ModelConfig, TrainConfig
 from .core import EpisodeSampler
 from .data import DevicePrefetcher, ImageFolderU8, ResidentLoader, StripedLoader, SyntheticImages
-from .parallel import GradAllReduce
+from .parallel import BucketedGradAllReduce
 from .training import Trainer
 
 
@@ -192,7 +192,8 @@ def train_main(main_config: MainConfig, model_config: ModelConfig, train_config:
     sampler = EpisodeSampler(marl_m, env, main_config.step)
     trainer = Trainer(nn_models, marl_m.nb_class, train_config.learning_rate, train_config.gamma,
                       metric_logger=metric_logger if rank == 0 else None,
-                      allreduce=GradAllReduce(world) if distributed else None,
+                      allreduce=(BucketedGradAllReduce(world, None, nn_models.flat_state().offsets, nn_models.flat_state().numel,
+                                                      device) if distributed else None),
                       exact_standardize_group=(dist.group.WORLD if distributed and world > 1 and
                                                exact_standardize else None))
     for e in range(train_config.nb_epoch):

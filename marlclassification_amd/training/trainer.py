@@ -71,7 +71,14 @@ class Trainer:
             allreduce_adv_stats(stats, self.__exact_group)
             gp, gl, gv, scalars, _ = eng.a2c_loss(out, y, self.__gamma, 2, self.__loss_bufs)
         flat = model.flat_state()
-        eng.episode_backward(gp, gl, gv, flat.grad_views())
+        bucketed = hasattr(self.__allreduce, "before_backward")  # parallel.BucketedGradAllReduce
+        if bucketed:
+            self.__allreduce.before_backward(eng)
+        try:
+            eng.episode_backward(gp, gl, gv, flat.grad_views())
+        finally:
+            if bucketed:
+                self.__allreduce.after_backward(eng)
         scale = 1.0 if self.__allreduce is None else self.__allreduce(flat.grads)
         flat.step += 1
         eng.adam(flat.params, flat.grads, flat.exp_avg, flat.exp_avg_sq, flat.step, self.__lr,

@@ -485,7 +485,7 @@ def test_two_rank_hip_trainer_matches_big_batch_update(device, exact):
 # ---- achieved errors per fixture (recorded for DESIGN.md) ------------------------------------------
 def test_record_achieved_errors(device):
     """Not a tolerance test: measures the achieved max |error| of every fixture against the
-    reference's goldens and writes them to gpurun_out/r05_achieved_errors.json (with the
+    reference's goldens and writes them to gpurun_out/r06_achieved_errors.json (with the
     sampled-index flips of the oracle-only cases that ran before it in this session)."""
     rec = {}
     for tag in ("g1_conftest", "g2_mnist_c1", "g3_mnist_ckpt", "g4_resisc_b2"):

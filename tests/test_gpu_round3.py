@@ -222,7 +222,7 @@ def test_graph_replay_survives_eager_iterations_and_lr_changes(device):
 def test_png_folder_loader_rate(device, tmp_path):
     """Trains from a generated PNG folder at 256 x 256 and measures what the loader sustains
     (images / s decoded + uploaded, one rank) next to what one training step consumes; the
-    numbers go to gpurun_out/r05_loader.json (DESIGN.md quotes them)."""
+    numbers go to gpurun_out/r06_loader.json (DESIGN.md quotes them)."""
     import numpy as np
     from PIL import Image
     from torch.utils.data import DataLoader
@@ -294,7 +294,7 @@ def test_png_folder_loader_rate(device, tmp_path):
     assert th.equal(first[0][0][0].cpu(), ds[idx0[0]][0]) and first[0][1][0].item() == ds[idx0[0]][1].item()
     rec["cpu_count"] = os.cpu_count()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_loader.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_loader.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print(json.dumps(rec))
     # more decode processes must not be slower than the training thread decoding alone

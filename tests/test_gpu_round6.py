@@ -41,3 +41,66 @@ def test_direct_engine_user_survives_a_knob_change_after_pack(device):
     fresh.configure(g.na, g.nb, g.ns, g.img.shape[1:])
     with pytest.raises(RuntimeError, match="no weights packed"):
         _run(fresh, g, device, g.nb)
+
+
+def _dp_bucket_worker(rank, world, port, bucketed, out_q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marlclassification_amd.fused import EpisodeDraws
+    from marlclassification_amd.parallel import BucketedGradAllReduce, GradAllReduce, broadcast_parameters, shard_bounds
+    from marlclassification_amd.training import Trainer
+    from tests.test_gpu_api import _golden_sampler
+
+    device = th.device("cuda:0")  # both ranks share the one GPU of the test box
+    g = Golden("g2_mnist_c1")
+    model, sampler = _golden_sampler(g, device)
+    flat = model.flat_state()
+    broadcast_parameters(flat.params)
+    lo, hi = shard_bounds(g.nb, rank, world)
+    i = g.inp
+    sampler.fixed_draws = EpisodeDraws(*(t.to(device) for t in (
+        i.pos0[:, lo:hi].contiguous(), i.h0[:, lo:hi].contiguous(), i.c0[:, lo:hi].contiguous(),
+        i.hc0[:, lo:hi].contiguous(), i.cc0[:, lo:hi].contiguous(), i.q[:, :, lo:hi].contiguous())))
+    hook = BucketedGradAllReduce(world, None, flat.offsets, flat.numel, device) if bucketed else GradAllReduce(world)
+    if bucketed:
+        assert hook.split is not None and 0 < hook.split < flat.numel
+    trainer = Trainer(model, g.cfg.nb_class, g.lr, g.gamma, allreduce=hook)
+    for _ in range(2):  # (two steps: the event is re-recorded, the side stream is re-joined)
+        trainer.train_step(g.img[lo:hi], g.y[lo:hi], sampler)
+    th.cuda.synchronize()
+    if rank == 0:
+        out_q.put((model.flat_state().params.cpu().numpy(), model.flat_state().grads.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_bucket_allreduce_gives_the_one_bucket_update(device):
+    """the heads' gradient slice is all-reduced on a side stream from the event the library
+    records ahead of the reverse loop (marl_backward_heads_event), the rest behind the backward pass - two HIP
+    Trainer processes over gloo: parameters and summed gradients after two steps are BIT-equal to the single
+    all-reduce of the flat buffer."""
+    import torch.multiprocessing as mp
+
+    from tests.test_gpu_round2 import _free_port
+
+    res = {}
+    for bucketed in (False, True):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_dp_bucket_worker, args=(r, 2, port, bucketed, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[bucketed] = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    import numpy as np
+
+    assert np.array_equal(res[False][0], res[True][0]), "parameters differ"
+    assert np.array_equal(res[False][1], res[True][1]), "summed gradients differ"

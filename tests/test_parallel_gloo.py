@@ -157,3 +157,49 @@ def test_resident_image_set_equals_the_streamed_batches():
     b = ShardedBatchSampler(part, 8, 1, 2, True, 2)
     for ia, ib in zip(a, b):
         assert not set(ia) & set(ib) and len(ia) == len(ib)
+
+
+def _bucket_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from marlclassification_amd.fused import FlatParams
+    from marlclassification_amd.parallel import HEAD_PREFIXES, BucketedGradAllReduce, GradAllReduce
+
+    g = Golden("g1_conftest")
+    flat = FlatParams({k: tuple(v.shape) for k, v in g.params.items()}, th.device("cpu"))
+    gen = th.Generator().manual_seed(100 + rank)
+    grads = th.randn(flat.numel, generator=gen)
+    one = grads.clone()
+    scale1 = GradAllReduce(world)(one)
+    ar = BucketedGradAllReduce(world, None, flat.offsets, flat.numel, th.device("cpu"))
+    two = grads.clone()
+    ar.before_backward(None)  # (CPU: no event to install; arms the two-collective form)
+    scale2 = ar(two)
+    ar.after_backward(None)
+    first_head = min(off for k, off in flat.offsets.items() if k.startswith(HEAD_PREFIXES))
+    # a layout whose heads are NOT the tail degrades to the single collective
+    shuffled = dict(reversed(list(flat.offsets.items())))
+    rev = FlatParams({k: tuple(g.params[k].shape) for k in shuffled}, th.device("cpu"))
+    if rank == 0:
+        out_q.put((bool(th.equal(one, two)), scale1 == scale2, ar.split == first_head and 0 < ar.split < flat.numel,
+                   BucketedGradAllReduce(world, None, rev.offsets, rev.numel, th.device("cpu")).split is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_bucket_gradient_exchange_equals_one_bucket():
+    """the heads' slice of the flat gradient buffer (the tail: policy, critic, prediction) and the
+    rest as two collectives give the same sums as one (world size 2, gloo, CPU); the split point is the first head
+    parameter; a layout with the heads elsewhere falls back to the single all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, scale_same, split_ok, fallback = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same and scale_same and split_ok and fallback

@@ -9,7 +9,7 @@ from oracle import marl_oracle as mo
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"  # prefix of the parity records the GPU tests write (copied into profiles/ after the box run)
+ROUND = "r06"  # prefix of the parity records the GPU tests write (copied into profiles/ after the box run)
 
 
 def record(name, obj):

@@ -3,7 +3,7 @@ launch of every kernel class of marl_profile_begin, = 2 x FETCH_SIZE (gfx950 cor
 coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both reported in KB.  The file is
 stamped with the sha256 of csrc/*.hip|*.h at profiling time; bench.py only quotes it while the
 sources it runs still hash to that value.
-usage: python tools/make_traffic_json.py r05"""
+usage: python tools/make_traffic_json.py r06"""
 import csv
 import json
 import os

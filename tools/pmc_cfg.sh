@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_cfg.sh c4|c5 [R]  -> profiles/${R}_bench_<cfg>_pmc_{fetch_size,write_size,mfma_busy}.csv
 # three separate rocprofv3 --pmc passes (counters of one pass only) of a short bench run of another BASELINE config
-CFG=$1; R=${2:-r05}
+CFG=$1; R=${2:-r06}
 export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 for pass in "fetch_size FETCH_SIZE" "write_size WRITE_SIZE" "mfma_busy SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do

@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box): R=r05 bash tools/round_profiles.sh
+# usage (on the GPU box): R=r06 bash tools/round_profiles.sh
 # Everything profiles/ holds for a round, from one box:
 #   kernel trace (+ --stats-equivalent summary) of the default bench command  -> ${R}_bench_c3_kernel_stats.csv
 #   separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES, waits, LDS, insts)
 #   ${R}_traffic.json stamped with the sha256 of csrc/*.hip|*.h (tools/make_traffic_json.py)
 #   un-profiled bench lines: c3 (with the CPU leg), rollout-only, c2 / c4 / c5 (+ their kernel stats)
-R=${R:-r05}
+R=${R:-r06}
 export TMPDIR=/tmp
 mkdir -p gpurun_out profiles
 P=profiles
