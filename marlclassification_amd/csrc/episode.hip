@@ -1226,9 +1226,13 @@ static void register_split_images(const Dims& d, const WLayout& w, const float* 
     }
 }
 
-static int unpack_grads(const Ctx& c, float* const* grads) {
+// which: 0 every parameter, 1 only the heads' matrices (MARL_P_POL_W0 .. MARL_P_PRE_B1: final before the reverse loop -
+// marl_backward_heads_event), 2 everything but those
+static int unpack_grads(const Ctx& c, float* const* grads, int which = 0) {
     PermQueue q(c.st);
     for (int i = 0; i < MARL_NPARAMS; ++i) {
+        const bool head = i >= MARL_P_POL_W0 && i <= MARL_P_PRE_B1;
+        if ((which == 1 && !head) || (which == 2 && head)) continue;
         const ParamMeta m = param_meta(c.d, i);
         if (m.kind == PK_MATRIX) {
             q.push(perm(c.gp(i), grads[i], m.n, m.k, m.k, 1, c.w.ldp[i], 0, 1, 1, 0));
@@ -1238,9 +1242,11 @@ static int unpack_grads(const Ctx& c, float* const* grads) {
             q.push(perm(c.gp(i), grads[i], m.n, m.k, m.k, 1, c.w.ldp[i], 0, 9, 1, ci));
         }
     }
-    // b_hh enters every gate sum exactly like b_ih: same gradient
-    q.push(perm(grads[MARL_P_LB_BIH], grads[MARL_P_LB_BHH], 1, 4 * c.d.n_b, 4 * c.d.n_b, 1, 0, 0, 1, 1, 0));
-    q.push(perm(grads[MARL_P_LA_BIH], grads[MARL_P_LA_BHH], 1, 4 * c.d.n_a, 4 * c.d.n_a, 1, 0, 0, 1, 1, 0));
+    if (which != 1) {
+        // b_hh enters every gate sum exactly like b_ih: same gradient
+        q.push(perm(grads[MARL_P_LB_BIH], grads[MARL_P_LB_BHH], 1, 4 * c.d.n_b, 4 * c.d.n_b, 1, 0, 0, 1, 1, 0));
+        q.push(perm(grads[MARL_P_LA_BIH], grads[MARL_P_LA_BHH], 1, 4 * c.d.n_a, 4 * c.d.n_a, 1, 0, 0, 1, 1, 0));
+    }
     q.flush();
     return q.rc;
 }
@@ -1447,10 +1453,12 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
 
     // Data parallelism (parallel.py, BucketedGradAllReduce): every gradient of the three heads' parameters (POL_*,
     // CRI_*, PRE_*) is complete here, ahead of the ~1.4 ms reverse loop - flush what they queued and mark the point.
-    if (hipEvent_t ev = g_heads_event) {
+    const bool heads_early = g_heads_event != nullptr;
+    if (heads_early) {
         if (c.tq) MARL_TRY(launch_tn_queue(tq, c.rq, st));
         MARL_TRY(rq.flush());
-        MARL_HIP_CHECK(hipEventRecord(ev, st));
+        MARL_TRY(unpack_grads(c, grads, 1));  // (their matrices leave the packed layout now; the end skips them)
+        MARL_HIP_CHECK(hipEventRecord(g_heads_event, st));
     }
 
     // ---- reverse-time loop over the recurrent chain ----------------------------------
@@ -1869,7 +1877,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     }
     if (c.tq) MARL_TRY(launch_tn_queue(tq, c.rq, st));  // the small weight gradients, one launch
     MARL_TRY(rq.flush());
-    return unpack_grads(c, grads);
+    return unpack_grads(c, grads, heads_early ? 2 : 0);
 }
 
 }  // namespace marl
