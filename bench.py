@@ -196,11 +196,14 @@ def matrix_products_note(lib, cfg) -> str:
         if plan(b"g3_lstm"):
             on.insert(0, "LSTM cells")
         if plan(b"g3_tn"):
-            on.append("the four large weight gradients")
+            on.append("the four large weight gradients" + (" (one launch per cell" + (", phase-pipelined step" if plan(b"g3_tn_pipe") else "")
+                                                            + ")" if plan(b"g3_tn_cell") else ""))
         note += ("; " + ", ".join(on) + " on operand images pre-split by their producers and staged by LDS-DMA "
                  "(gemm3.hip; marl_plan_query)")
         if plan(b"small_r"):
             note += "; small-batch tile plans (tiles < 2 x CUs)"
+        if plan(b"wgrad3"):
+            note += "; conv weight gradients with >= 16 input channels on the same six-product arithmetic (cnn_wgrad3_kernel)"
     return note
 
 

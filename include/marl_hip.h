@@ -346,7 +346,11 @@ int marl_debug_buffer(const marl_config* cfg, int train, const char* name, int t
  * note, tests): key "g3" = the large matrix products of this batch run on operand images (gemm3.hip),
  * "g3_model" = the weights workspace holds the k16 weight images (a property of the MODEL and the knobs only:
  * the weights layout never moves with the batch), "g3_tn" = the four large weight gradients run on images,
- * "g3_lstm" = the fused LSTM launch does, "small_r" = the small-batch tile plans are selected.  *value = 0 / 1. */
+ * "g3_lstm" = the fused LSTM launch does, "lstm_plan" = the tile plan that launch takes (the launcher's own rule: 2 =
+ * 128-row tiles, 3 / 4 = the gate-split small-batch plans, 1 / 5 / 6 by knob), "small_r" = lstm_plan is 3 or 4,
+ * "g3_tn_cell" = both weight gradients of an LSTM cell come from one launch, "g3_tn_pipe" = the row contractions run
+ * the phase-pipelined step, "wgrad3" = conv weight gradients (cin >= 16) on the bf16 pipe.  *value = 0 / 1 (a plan
+ * number for "lstm_plan"). */
 int marl_plan_query(const marl_config* cfg, int train, const char* key, int* value);
 
 #ifdef __cplusplus

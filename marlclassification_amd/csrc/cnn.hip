@@ -1456,14 +1456,7 @@ int launch_cnn_fwd(CnnFwdArgs& a, hipStream_t st) {
     }
     // as many patches per workgroup as fit three workgroups per CU (the conv weights are
     // re-read from L2 by every workgroup), but keep >= 256 workgroups
-    static int rb_max = 0, lds_cap = 0;
-    if (!rb_max) {
-        const char* e = getenv("MARL_CNN_RB");
-        rb_max = e ? atoi(e) : 8;
-        if (rb_max < 1 || rb_max > 16) rb_max = 8;  // <= 16: per-patch LDS tables
-        const char* c = getenv("MARL_CNN_LDS_KB");
-        lds_cap = c ? atoi(c) : 52;
-    }
+    constexpr int rb_max = 8, lds_cap = 52;  // patches per workgroup (<= 16: per-patch LDS tables), LDS cap in KB
     int rb = rb_max;
     while (rb > 1 && (cnn_fwd_plan(a, rb) * sizeof(float) > (size_t)lds_cap * 1024 || cdiv(a.rows, rb) < 256)) --rb;
     const size_t lds = cnn_fwd_plan(a, rb) * sizeof(float);
@@ -2020,8 +2013,8 @@ static int cnn_dgrad_rb(CnnDgradArgs& a) {
     const int nt = (a.cin + 15) / 16;
     const int wpn = 8 / nt;
     if (wpn < 1) return 0;
-    const int rb_max = tune_get("dgrad_rb", 8);
-    const size_t lds_cap = (size_t)tune_get("dgrad_lds_kb", 72) * 1024;
+    const int rb_max = 8;
+    const size_t lds_cap = (size_t)72 * 1024;
     for (int rb = rb_max < 8 ? (rb_max < 1 ? 1 : rb_max) : 8; rb >= 1; --rb) {
         if (cnn_dgrad_plan(a, rb) * sizeof(float) > lds_cap) continue;
         if (a.MT > kDgradTiles * wpn || a.MT > 64) continue;
@@ -2043,12 +2036,17 @@ int cnn_dgrad_supported(const CnnDgradArgs& a0) {
 
 // can the launch that produces dZ_0 also form layer 0's weight gradient? (cin = layer 0's output channels: one
 // 16-wide tile; K0 = 9 * cin0 <= 32: two k tiles)
-// OPT-IN (knob dgrad_w0 = 1): measured SLOWER than the separate first-layer launch on every BASELINE shape (C3 7.68
+// EXPERIMENT BUILD ONLY (EXTRA=-DMARL_DGRAD_W0; round 5's knob dgrad_w0 is gone): measured SLOWER than the separate first-layer launch on every BASELINE shape (C3 7.68
 // vs 7.59 ms, C4 3.71 vs 3.63, C5 18.45 vs 18.25: DESIGN 4.0c) - the extra phase adds two barriers, a scattered
 // pixel gather and ~4 us of dependent latency to each chunk of a kernel that is a latency chain already, which costs
 // more than the 100 us launch and the dZ_0 round trip it removes.
 int cnn_dgrad_w0_ok(const CnnDgradArgs& a, int cin0, int f0) {
-    return tune_get("dgrad_w0", 0) != 0 && a.cin <= 16 && 9 * cin0 <= 32 && cin0 >= 1 && (f0 - 1) / 2 + 1 == a.hin;
+#ifdef MARL_DGRAD_W0  // experiment build only (make EXTRA=-DMARL_DGRAD_W0): the form lost every A/B, the product does not carry it
+    return a.cin <= 16 && 9 * cin0 <= 32 && cin0 >= 1 && (f0 - 1) / 2 + 1 == a.hin;
+#else
+    (void)a, (void)cin0, (void)f0;
+    return 0;
+#endif
 }
 
 // Persistent grid: as many workgroups as are resident at once (occupancy x CUs), never more than
@@ -2068,8 +2066,12 @@ static int cnn_dgrad_grid(const CnnDgradArgs& a, int rb, size_t lds) {
     for (int i = 0; i < occ_n; ++i)
         if (occ_lds[i] == key) occ = occ_val[i];
     if (!occ) {
+#ifdef MARL_DGRAD_W0
         const void* kern = a.w0 ? reinterpret_cast<const void*>(cnn_dgrad_kernel<true>)
                                      : reinterpret_cast<const void*>(cnn_dgrad_kernel<false>);
+#else
+        const void* kern = reinterpret_cast<const void*>(cnn_dgrad_kernel<false>);
+#endif
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds) != hipSuccess || occ < 1) occ = 1;
         if (occ_n < 8) {
             occ_lds[occ_n] = key;
@@ -2087,8 +2089,10 @@ static void cnn_dgrad_raise_lds() {
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+#ifdef MARL_DGRAD_W0
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cnn_dgrad_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+#endif
         raised = true;
     }
 }
@@ -2129,9 +2133,16 @@ int launch_cnn_dgrad(CnnDgradArgs& a, hipStream_t st) {
         set_error("fused CNN layer backward: first-layer weight gradient without its buffers");
         return MARL_EINVAL;
     }
+#ifdef MARL_DGRAD_W0
     if (a.w0)
         hipLaunchKernelGGL(cnn_dgrad_kernel<true>, dim3((unsigned)grid), dim3(512), lds, st, a);
     else
+#else
+    if (a.w0) {
+        set_error("cnn_dgrad: the fused first-layer form is not in this build");
+        return MARL_EINVAL;
+    }
+#endif
         hipLaunchKernelGGL(cnn_dgrad_kernel<false>, dim3((unsigned)grid), dim3(512), lds, st, a);
     prof_after(5, st);
     MARL_LAUNCH_CHECK();
@@ -2761,7 +2772,7 @@ static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
     a.dcin = make_fdiv(a.cin);
     if (best_nkt == 0) return 0;
     const int lds_cap_kb = tune_get("wgrad3_lds_kb", best_nkt == 9 ? 150 : 76);
-    int rb_cap = tune_get("wgrad3_rb", 16);
+    int rb_cap = 16;
     if (rb_cap < 1) rb_cap = 1;
     for (int v = 0; v < 2; ++v) {
         const int PD = kWgPref[0][v][0], PI = kWgPref[0][v][1];
@@ -2851,10 +2862,10 @@ static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
     a.dpe = make_fdiv(a.cin * a.hin * a.hin);
     a.dff = make_fdiv(a.hin * a.hin);
     a.df = make_fdiv(a.hin);
-    const int lds_cap_kb = tune_get("wgrad_lds_kb", 76);
-    int rb_cap = tune_get("wgrad_rb", 16);
+    const int lds_cap_kb = 76;
+    int rb_cap = 16;
     if (rb_cap < 1) rb_cap = 1;
-    const int wg_per_cu = tune_get("wgrad_wgs", 0);  // 0 = by layer size
+    const int wg_per_cu = 0;  // 0 = by layer size
     const size_t red = a.ms > 1 ? (size_t)8 * bct * bkt * 256 : 0;
     // the shallow prefetch variant first (fewer registers -> two workgroups per CU)
     for (int v = 0; v < 2; ++v) {

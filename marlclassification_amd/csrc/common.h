@@ -217,6 +217,7 @@ G3Prob g3_prob(const void* a3, int a_row0, const void* b3, int b_row0, int k, fl
 void g3_add_seg(G3Prob& p, const void* a3, int a_row0, const void* b3, int b_row0, int k);
 int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant = 0);
 int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant = 0);
+int g3_lstm_plan(const G3Batch& batch);  // the tile plan launch_gemm_lstm3 takes for this batch (marl_plan_query reports it)
 // weight-gradient form: contraction over the ROWS of two images (gemm_tn3_kernel)
 struct G3TnArgs {
     const char* a3;
@@ -250,7 +251,7 @@ struct G3TnCell {
     G3TnArgs t[kMaxTnCell];  // one entry per column tile: 256-wide ones first, then (at most one) 128-wide
     int nt, n256;            // tiles in all, 256-wide ones
     int gx, gz;
-    int halves_last, teams;  // dispatch order (see the kernel)
+    int teams;               // equal-work team dispatch (see the kernel)
 };
 bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows);
 G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows);

@@ -217,7 +217,7 @@ static bool g3_model_ok(const Dims& d) {
            d.n_a >= mu;
 }
 static bool g3_enabled(const Dims& d) {
-    return g3_model_ok(d) && d.R % 32 == 0 && d.R >= tune_get("g3_min_rows", 32);
+    return g3_model_ok(d) && d.R % 32 == 0 && d.R >= 32;
 }
 // the four large weight gradients on images (gemm_tn3_kernel: 256-column tiles of A, whole 256 x 256 tiles
 // or column passes, g3_tn_plan): only where that form wins - >= 32768 contraction rows (at C4's 8192 rows the
@@ -633,7 +633,7 @@ static int make_ctx(const marl_config* cfg, const void* wws, size_t wbytes, void
     // stand-alone kernel) one image pass over U[t] runs ahead of the LSTM launch
     CnnFwdArgs probe = cnn_fwd_shape(c.d);  // (with the fragment-order weight copies the AidCnn kernels ask for)
     for (int l = 0; l < c.d.L; ++l) probe.layer[l].wfrag = c.w.wf[4 * l] ? c.W + c.w.wf[4 * l] : nullptr;
-    c.u3_by_producers = c.e.g3 && tune_get("g3_lstm", 1) != 0 && tune_get("g3_u3", 1) != 0 && c.e.fused_fwd &&
+    c.u3_by_producers = c.e.g3 && tune_get("g3_lstm", 1) != 0 && c.e.fused_fwd &&
                         cnn_fwd_writes_image(probe) && use_panels(c.d) && !use_side_stream() &&
                         ((c.d.nf | c.d.n_mo | c.d.n_d) & 3) == 0 &&
                         // (the producers write exactly nin columns: a K pad of the last 16-deep step would be
@@ -1017,13 +1017,10 @@ static SideStream g_side;
 
 static bool use_side_stream() {
     static int enabled = -1;
-    if (enabled < 0) {
-        // measured on MI355X (C3): no gain (16.38 vs 16.28 ms / iteration) - the cross-stream
-        // event waits cost what the overlap buys - so it is opt-in
-        const char* e = getenv("MARL_STREAMS");
-        enabled = (e && e[0] == '1') ? 1 : 0;
-    }
-    return enabled != 0;
+    // measured on MI355X (C3, rounds 1-2): no gain (16.38 vs 16.28 ms / iteration; round 2: 11.15 vs 10.23) - the
+    // cross-stream event waits cost what the overlap buys.  The environment switch is gone; the form stays for reference.
+    (void)enabled;
+    return false;
 }
 
 // critic + prediction heads on `rows` rows starting at state slice t0 (+1)
@@ -1384,7 +1381,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     if (defer) c.rq = &rq;
     if (defer) c.tq = &tq;
     c.defer_slabs = defer == 2;
-    c.defer_small = defer == 3 ? (size_t)tune_get("red_defer_kb", 8192) * 1024 : 0;
+    c.defer_small = defer == 3 ? (size_t)8192 * 1024 : 0;
     const Dims& d = c.d;
     hipStream_t st = c.st;
     const int64_t NR = d.NR;
@@ -1482,7 +1479,7 @@ static int episode_backward(const Ctx& c0, const void* img, int img_u8, const fl
     const bool chain = ride && use_chain(d);
     const bool g3 = c.e.g3;  // the gate gradients also leave as k16 images; the products below read those
     // every consumer on images (in-loop batch, dU, the four weight gradients): no fp32 copy of them at all
-    const int skip_f32 = g3 && dl_in_loop && g3_tn_enabled(d) && tune_get("g3_skip_f32", 1) != 0;
+    const int skip_f32 = g3 && dl_in_loop && g3_tn_enabled(d);
     const int pln_blocks = chain ? panel_chain_blocks(d.na, d.nb) : panel_bwd_blocks(R);
     for (int t = ns - 1; t >= 0; --t) {
         const int first = (t == ns - 1);
@@ -2316,10 +2313,27 @@ int marl_plan_query(const marl_config* cfg, int train, const char* key, int* val
     else if (!strcmp(key, "g3_model")) *value = g3_model_ok(d);
     else if (!strcmp(key, "g3_lstm")) *value = g3_enabled(d) && tune_get("g3_lstm", 1) != 0;
     else if (!strcmp(key, "g3_tn")) *value = g3_enabled(d) && g3_tn_enabled(d);
-    else if (!strcmp(key, "small_r")) {  // the gate-split LSTM plans (gemm3.hip, g3_lstm_plan): tiles of 128 rows < 192
-        const int64_t t128 = cdiv(d.R, 128) * (cdiv(d.n_b, 32) + cdiv(d.n_a, 32));
-        *value = g3_enabled(d) && tune_get("g3_lstm", 1) != 0 && t128 < tune_get("g3_lstm_small_tiles", 192);
+    else if (!strcmp(key, "lstm_plan") || !strcmp(key, "small_r")) {
+        // the tile plan the fused two-cell LSTM launch takes (gemm3.hip: 2 = 128-row tiles, 3 / 4 = the 32- / 64-row
+        // gate-split plans, 1 / 5 / 6 by knob) - asked of the launcher's own rule with the shapes of the launch (ADVICE
+        // r5: this used to re-derive the threshold by hand); "small_r" = one of the gate-split plans
+        int plan = 0;
+        if (g3_enabled(d) && tune_get("g3_lstm", 1) != 0) {
+            G3Batch b{};
+            b.count = 2;
+            b.p[0].m = b.p[1].m = (int)d.R;
+            b.p[0].n = d.n_b;
+            b.p[1].n = d.n_a;
+            plan = tune_get("g3_lstm_variant", 0);
+            if (!plan) plan = g3_lstm_plan(b);
+        }
+        *value = !strcmp(key, "small_r") ? (plan == 3 || plan == 4) : plan;
     }
+    else if (!strcmp(key, "g3_tn_cell"))  // both weight gradients of a cell from one launch (gemm_tn3_cell_kernel)
+        *value = g3_enabled(d) && g3_tn_enabled(d) && g3_tn_cell_ok(4 * d.n_b, d.nin, d.n_b, d.NR) &&
+                 g3_tn_cell_ok(4 * d.n_a, d.nin, d.n_a, d.NR);
+    else if (!strcmp(key, "g3_tn_pipe")) *value = tune_get("g3_tn_pipe", 1) != 0;  // phase-pipelined row contractions
+    else if (!strcmp(key, "wgrad3")) *value = tune_get("wgrad3", 1) != 0;  // conv weight gradients on the bf16 pipe (cin >= 16)
     else {
         set_error("unknown plan key %s", key);
         return MARL_EINVAL;

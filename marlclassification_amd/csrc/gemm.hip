@@ -904,7 +904,7 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     batch.xcd_map = xcd_map_enabled() || (batch.count == 1 && !LSTM && tune_get("nt_xcd", 1));
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     constexpr size_t lds2 = (size_t)2 * (GROUPS * BM + BN) * (32 + 4) * sizeof(float);
-    batch.single_buf = GROUPS == 1 && !LSTM && BM == 128 && tune_get("nt_single", 1);
+    batch.single_buf = GROUPS == 1 && !LSTM && BM == 128 && true;
     // (LSTM instantiation: s_setprio(1) around the matrix phase - the scheduler prefers the wave
     // that is feeding the matrix pipe over a co-resident one that is staging: -3 % on the launch.
     // Compile-time only: even a never-taken run-time branch around the cluster cost the other
@@ -923,26 +923,12 @@ static int launch_nt_variant(dim3 grid, const GemmBatch& batch_in, hipStream_t s
     return MARL_OK;
 }
 
-int xcd_map_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("MARL_XCD_MAP");
-        on = (e && e[0] == '1') ? 1 : 0;  // opt-in: measured neutral-to-negative on this workload
-    }
-    return on;
-}
+int xcd_map_enabled() { return 0; }  // (the fp32-operand NT kernels: measured neutral-to-negative; the image kernels map by knob nt_xcd / tn_xcd)
 
 // 1 = plain 4-wave loop (default), 2 = ping-pong wave groups (MARL_GEMM_GROUPS=2).  Measured on
 // MI355X: the two-group schedule gains 2-7 % on single large products (M = 65536) but loses
 // on this workload's small / batched products (bigger tiles -> worse tail), so it is opt-in.
-static int gemm_groups() {
-    static int g = 0;
-    if (!g) {
-        const char* e = getenv("MARL_GEMM_GROUPS");
-        g = (e && atoi(e) == 2) ? 2 : 1;
-    }
-    return g;
-}
+static int gemm_groups() { return 1; }
 
 static int check_prob(const GemmProb& p) {
     for (int s = 0; s < p.nseg; ++s) {
@@ -989,7 +975,7 @@ int launch_gemm_nt(const GemmBatch& batch, hipStream_t st) {
     prof_before(1, st);
     if (split_mode()) {
         MARL_TRY(launch_gemm_nt_split(batch, max_m, max_n, blocks128, st));
-    } else if (blocks128 >= tune_get("nt_min_blocks128", 256) && max_n >= 96) {
+    } else if (blocks128 >= 256 && max_n >= 96) {
         const int g = gemm_groups();
         dim3 grid((unsigned)cdiv(max_m, 128 * g), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         if (g == 2)
@@ -1095,7 +1081,7 @@ static TnPlan tn_plan(int ni, int nj, int64_t rows) {
     p.bm = (ni >= 96 && nj >= 96 && cdiv(ni, 128) * cdiv(nj, 128) >= 4) ? 128 : 64;
     const int64_t tiles = cdiv(ni, p.bm) * cdiv(nj, p.bm);
     // (the bf16x6 kernel keeps two workgroups per CU resident, the fp32 one three)
-    const int target = (p.bm == 128 && split_mode()) ? tune_get("tn_split_wgs", 512) : tune_get("tn_target_wgs", 768);
+    const int target = (p.bm == 128 && split_mode()) ? 512 : 768;
     int64_t s = cdiv(target, tiles);
     const int64_t max_s = cdiv(rows, 4 * BK);  // at least 4 K tiles per split
     if (s > max_s) s = max_s;
@@ -1187,7 +1173,7 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
         return MARL_EINVAL;
     }
     TnPlan p = tn_plan(ni, nj, rows);
-    if (tq && q && p.bm == 64 && tune_get("tn_batch", 1) != 0) {  // small product: runs with the others, later
+    if (tq && q && p.bm == 64) {  // small product: runs with the others, later
         if (tq->n == kMaxTnBatch) MARL_TRY(launch_tn_queue(*tq, q, st));
         tq->it[tq->n++] = TnQueue::Item{a, b, c, colsum_out, lda, ldb, ldc, ni, nj, rows};
         return MARL_OK;
@@ -1230,8 +1216,8 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     // s_setprio(1) around the matrix phase (see launch_nt_variant): -3 % on the weight gradients.
     // (Kept behind this run-time flag on purpose: the unconditional form compiles to a 20 % SLOWER
     // loop - measured 307 vs 254 us - the branch changes how hipcc schedules the cluster.)
-    const int tn_prio = tune_get("tn_prio", 1);
-    static const int tbk = (getenv("MARL_TN_BK") && atoi(getenv("MARL_TN_BK")) == 16) ? 16 : 32;
+    const int tn_prio = 1;
+    constexpr int tbk = 32;
 #define MARL_TN_LAUNCH(BM_, BK_)                                                               \
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, 2, 2, BK_>), grid, dim3(256),                 \
                        (size_t)2 * BK_ * 2 * BM_ * sizeof(float), st, a, lda, b, ldb, out, ldo, \
@@ -1239,7 +1225,7 @@ int launch_gemm_tn(const float* a, int lda, const float* b, int ldb, float* c, i
     if (p.bm == 128 && split_mode())
         MARL_TRY(launch_gemm_tn_split(a, lda, b, ldb, out, ldo, stride, ni, nj, rows, p.rows_per_split, csum,
                                       grid, gx, gy, gz, st));
-    else if (p.bm == 128 && tbk == 32 && tune_get("tn_bufs", 1) == 1)
+    else if (p.bm == 128 && tbk == 32)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256),
                            (size_t)32 * 2 * 128 * sizeof(float), st, a, lda, b, ldb, out, ldo, stride, ni, nj,
                            rows, p.rows_per_split, csum, gx, gy, gz, tn_prio);

@@ -1312,21 +1312,7 @@ template <bool PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_tn3_cell_kernel(const G3TnCell P) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     unsigned bx, by, bz;
-    if (P.halves_last) {
-        // per XCD: the 256-wide tiles of its slabs first (team order), its 128-wide tiles behind them - whole
-        // rounds of equal workgroups (gz % 8 == 0, nt == n256 + 1: checked by the launcher)
-        const unsigned L = blockIdx.x, xcd = L & 7, slot = L >> 3, ns = P.gz >> 3;
-        const unsigned full = ns * P.gx * P.n256;
-        unsigned q = slot < full ? slot : slot - full;
-        if (slot < full) {
-            by = q % P.n256;
-            q /= P.n256;
-        } else {
-            by = P.n256;
-        }
-        bx = q % P.gx;
-        bz = xcd * ns + q / P.gx;
-    } else if (P.teams) {
+    if (P.teams) {
         // equal-work teams: per (row slab, PAIR of 256-column tiles of G): the 256-wide column tiles of both G tiles
         // and ONE 512 (both G tiles) x 128 workgroup for the narrow last column tile - 2 n256 + 1 workgroups of the
         // same length that walk the slab in step (a 256 x 128 tile would run twice as fast, away from its team)
@@ -1433,7 +1419,7 @@ static int launch_g3_variant(G3Batch batch, int max_m, int max_n, hipStream_t st
     bool same = true;
     for (int i = 1; i < batch.count; ++i) same = same && batch.p[i].m == batch.p[0].m && batch.p[i].n == batch.p[0].n;
     batch.xcd_map = tune_get("nt_xcd", 1) &&
-                    (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1 || (same && tune_get("nt_xcd_multi", 1) != 0));
+                    !LSTM && (batch.count == 1 || same);  // (the two-cell LSTM launch keeps the dispatch order: measured twice)
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     batch.safe = tune_get("g3_safe", 0);
     constexpr size_t lds = (size_t)NST * (BM + BN) * kImgRowBytes;
@@ -1488,7 +1474,7 @@ static int launch_g3p_variant(G3Batch batch, int max_m, int max_n, hipStream_t s
     batch.gy = (int)grid.y;
     bool same = true;
     for (int i = 1; i < batch.count; ++i) same = same && batch.p[i].m == batch.p[0].m && batch.p[i].n == batch.p[0].n;
-    batch.xcd_map = tune_get("nt_xcd", 1) && (LSTM ? tune_get("lstm_xcd", 0) != 0 : batch.count == 1 || same);
+    batch.xcd_map = tune_get("nt_xcd", 1) && !LSTM && (batch.count == 1 || same);
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     batch.safe = tune_get("g3_safe", 0);
 #ifndef MARL_G3_ABLATE
@@ -1545,18 +1531,16 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
     }
     if (!variant) variant = tune_get("g3_nt_variant", 0);
     if (!variant) {
-        // Tile plans by launch size (tools/small_r_lab.py, profiles/r05_small_r_lab.json; each knob overrides):
+        // Tile plans by launch size (tools/small_r_lab.py, profiles/r05_small_r_lab.json):
         // big = one product with >= 1024 tiles of 128 x 128, mid = >= 256, small = everything else (the in-loop
         // backward batch at every batch size, the narrow heads, all launches of a 32-image batch).  Wave tiles
         // of 32 x 32 (plans 7, 11, 12: ~85 registers, 3-4 workgroups per CU) hide the ring's barriers better than
         // 64 x 64 ones wherever the launch is not long enough to amortise a 12 us prologue + epilogue.
-        const int v_big = tune_get("g3_nt_v_big", 2), v_mid = tune_get("g3_nt_v_mid", 2),
-                  v_small = tune_get("g3_nt_v_small", 7);
-        variant = max_n < 96 ? v_small : blocks128 >= 1024 ? v_big : blocks128 >= tune_get("g3_nt_mid_blocks", 256) ? v_mid : v_small;
+        variant = max_n >= 96 && blocks128 >= 256 ? 2 : 7;
         // round 6: ONE long product whose width is a whole number of 256-column tiles (dU: [Ns R x 256] over both cells'
         // gate gradients) -> the phase-pipelined 256 x 256 plan: A is read once instead of once per 128-column tile
         // (lab 182 -> 165 us on [65536 x 256 x 1024]; iteration -0.02 ms; the heads, n = 384, keep 128 x 128: 88 vs 78 us)
-        if (variant == 2 && blocks128 >= 1024 && batch.count == 1 && max_n % 256 == 0 && tune_get("g3_nt_p256", 1) != 0) variant = 21;
+        if (variant == 2 && blocks128 >= 1024 && batch.count == 1 && max_n % 256 == 0) variant = 21;
     }
     prof_before(1, st);
     int rc;
@@ -1600,8 +1584,8 @@ int g3_lstm_plan(const G3Batch& batch) {
     }
     // measured (two cells, n = 256, K = 880): R = 512: 35.0 / 22.9 / 18.6 us (128-row / 64-row / 32-row plan),
     // R = 1024: 37.3 / 28.9 / 27.4, R = 2048: 45.3 / 47.0 / 56.1, R = 4096: 63-65 / 66-68 / 84
-    if (t128 >= tune_get("g3_lstm_small_tiles", 192)) return 2;
-    return t64 >= tune_get("g3_lstm_small_tiles64", 384) ? 4 : 3;
+    if (t128 >= 192) return 2;
+    return t64 >= 384 ? 4 : 3;
 }
 
 int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
@@ -1752,7 +1736,7 @@ static void tn_cell_tiles(int nj, int& n256, int& n128) {
     else if (rem > 0) n128 = 1;
 }
 bool g3_tn_cell_ok(int ni, int nj_ih, int nj_hh, int64_t rows) {
-    if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < tune_get("g3_tn_cell_min_rows", 8192) || (rows & 31)) return false;
+    if (tune_get("g3_tn_cell", 1) == 0 || ni < 256 || rows < 8192 || (rows & 31)) return false;
     int a256, a128, b256, b128;
     tn_cell_tiles(nj_ih, a256, a128);
     tn_cell_tiles(nj_hh, b256, b128);
@@ -1763,7 +1747,7 @@ static bool g3_tn_cell_teams(int ni, int nj_ih, int nj_hh) {
     int a256, a128, b256, b128;
     tn_cell_tiles(nj_ih, a256, a128);
     tn_cell_tiles(nj_hh, b256, b128);
-    return tune_get("g3_tn_cell_teams", 1) != 0 && a128 + b128 == 1 && ni % 512 == 0;
+    return a128 + b128 == 1 && ni % 512 == 0;
 }
 G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
     G3TnPlan p;
@@ -1771,15 +1755,14 @@ G3TnPlan g3_tn_cell_plan(int ni, int nj_ih, int nj_hh, int64_t rows) {
     // ONE round of equal workgroups: every workgroup of the launch is resident at once (<= 256: one per CU), walks a
     // long row slab and writes one partial tile - measured against 3 rounds of a third the length (760 workgroups):
     // C3 7.37 vs 7.47 ms, C5 17.60 vs 17.78 (a third of the partial-slab traffic, no dispatch stagger inside a team);
-    // two rounds: no gain.  Knob g3_tn_cell_splits overrides.
+    // two rounds: no gain.
     int a256, a128, b256, b128;
     tn_cell_tiles(nj_ih, a256, a128);
     tn_cell_tiles(nj_hh, b256, b128);
     const int n256 = a256 + b256, n128 = a128 + b128;
     const int64_t per_slab = g3_tn_cell_teams(ni, nj_ih, nj_hh) ? (int64_t)(ni / 512) * (2 * n256 + 1)
                                                                 : (int64_t)cdiv(ni, 256) * (n256 + n128);
-    int64_t s = tune_get("g3_tn_cell_splits", 0);
-    if (s <= 0) s = (int64_t)tune_get("g3_tn_cell_rounds", 1) * 256 / (per_slab > 0 ? per_slab : 1);
+    int64_t s = 256 / (per_slab > 0 ? per_slab : 1);
     const int64_t max_s = cdiv(rows, 256);
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -1835,8 +1818,7 @@ int launch_gemm_tn3_cell(G3TnArgs ih, G3TnArgs hh, const G3TnPlan& plan, hipStre
     c.nt = n;
     c.gx = (int)cdiv(ih.ni, 256);
     c.gz = plan.splits;
-    c.halves_last = tune_get("g3_tn_cell_order", 0) == 1 && have128 && (c.gz & 7) == 0;
-    c.teams = !c.halves_last && have128 && g3_tn_cell_teams(ih.ni, ih.nj, hh.nj);
+    c.teams = have128 && g3_tn_cell_teams(ih.ni, ih.nj, hh.nj);
     const unsigned total = c.teams ? (unsigned)((c.gx >> 1) * (2 * c.n256 + 1) * c.gz) : (unsigned)(c.gx * c.nt * c.gz);
     constexpr size_t lds = (size_t)3 * 32 * 16 * kImgRowBytes;
     static bool raised = false;

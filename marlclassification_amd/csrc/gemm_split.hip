@@ -654,7 +654,7 @@ static int launch_nt_split_variant(dim3 grid, const GemmBatch& batch_in, hipStre
     batch.xcd_map = batch.count == 1 && !LSTM && tune_get("nt_xcd", 1);
     if (batch.xcd_map) grid = dim3(grid.x * grid.y * grid.z);
     // every B operand a registered weight matrix: the kernel copies their pre-split tiles
-    bool pre = tune_get("split_pre", 1) != 0;
+    bool pre = true;
     for (int i = 0; i < batch.count && pre; ++i)
         for (int sg = 0; sg < batch.p[i].nseg && pre; ++sg) {
             GemmSeg& g = batch.p[i].seg[sg];
@@ -681,7 +681,7 @@ static int launch_nt_split_variant(dim3 grid, const GemmBatch& batch_in, hipStre
 
 int launch_gemm_nt_split(const GemmBatch& batch, int max_m, int max_n, int64_t blocks128, hipStream_t st) {
     // 128-wide column tiles when they fill the chip (two workgroups per CU), else 128 x 64
-    if (blocks128 >= tune_get("nts_min_blocks128", 384) && max_n >= 96) {
+    if (blocks128 >= 384 && max_n >= 96) {
         dim3 grid((unsigned)cdiv(max_m, 128), (unsigned)cdiv(max_n, 128), (unsigned)batch.count);
         return launch_nt_split_variant<128, false>(grid, batch, st);
     }

@@ -516,7 +516,7 @@ int launch_panel_fwd(PanelFwdBatch& b, hipStream_t st) {
             MARL_HIP_CHECK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelMaxLds));
         raised = true;
     }
-    b.ln_narrow_max = tune_get("panel_ln_narrow", 1) ? 128 : 0;  // widths that take the two-slot row pass
+    b.ln_narrow_max = 128;  // widths that take the two-slot row pass
     unsigned pblocks = 0;
     for (int i = 0; i < b.count; ++i) {
         const PanelFwdProb& p = b.p[i];
@@ -963,7 +963,7 @@ int launch_panel_bwd(PanelBwdProb& p, hipStream_t st) {
     bool tail_lds = (Ll.k_in & 3) == 0 && (p.lddx & 3) == 0 &&
                     (!p.has_cellb || ((p.cellb.n & 3) == 0 && (p.cellb.ldg & 3) == 0 && (p.cellb.ldc & 3) == 0 &&
                                       (p.cellb.lddc & 3) == 0 && p.cellb.n == Ll.k_in)) &&
-                    tune_get("panel_tail_lds", 1) != 0;
+                    true;
 plan:  // (second pass without the LDS tail when the extra output panel does not fit)
     waves = 8;
     pmax = nmax = prm = 0;
@@ -1025,7 +1025,7 @@ plan:  // (second pass without the LDS tail when the extra output panel does not
     const int rec = ts_begin(&d_ts, calls++);
     p.ts = rec ? d_ts : nullptr;
 #endif
-    const int maxc = nmax <= 128 && tune_get("panel_bwd_maxc", 1) ? 2 : kBwdMaxCols;
+    const int maxc = nmax <= 128 ? 2 : kBwdMaxCols;
     if (p.has_cell) {
         p.panel_blocks = (int)pblocks;
         const unsigned cblocks = (unsigned)cdiv(p.cell_rows * (p.cell_vec4 ? p.cell.n / 4 : p.cell.n), 64 * waves);

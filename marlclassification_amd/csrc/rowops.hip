@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void gn_silu_fwd_flat_kernel(
 }
 
 static bool gn_flat_ok(int P, int C) {
-    return (C & (C - 1)) == 0 && C >= 4 && C <= 64 && P * C <= 64 * 16 && !getenv("MARL_GN_OLD");
+    return (C & (C - 1)) == 0 && C >= 4 && C <= 64 && P * C <= 64 * 16;
 }
 int gn_fwd_im2col_supported(int P, int C) { return gn_flat_ok(P, C) ? 1 : 0; }
 
@@ -980,11 +980,11 @@ int launch_gn_silu_bwd(const float* da, int64_t ldda, int da_chw, const float* z
     const int w = bwd_waves(C);
     const int rpw = bwd_rows_per_wave(rows, w);
     const bool pow2 = (C & (C - 1)) == 0 && C <= 256 && C >= 4;
-    if (pow2 && !getenv("MARL_GN_OLD")) {
+    if (pow2) {
         const dim3 grid((unsigned)gn_bwd_blocks(rows, C)), blk(64 * w);
         const size_t lds = (size_t)w * 2 * C * sizeof(float);
         const int U = C <= 64 ? 1 : C / 64, E = P * C;
-        if (E % (64 * U) == 0 && E / (64 * U) <= 4 && tune_get("gn_rowreg", 1)) {
+        if (E % (64 * U) == 0 && E / (64 * U) <= 4) {
             const int ne = E / (64 * U);
 #define MARL_GN_RR(U_, NE_)                                                                        \
     hipLaunchKernelGGL((gn_silu_bwd_rowreg_kernel<U_, NE_>), grid, blk, lds, st, da, ldda, da_chw, z, \
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs A) {
 
 int launch_sample(const SampleArgs& a, hipStream_t st) {
     if (a.nA > MARL_MAX_ACTIONS) return MARL_ELIMIT;
-    if (a.nA <= 4 && tune_get("sample_maxa4", 1))
+    if (a.nA <= 4)
         hipLaunchKernelGGL(sample_kernel<4>, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(sample_kernel<MARL_MAX_ACTIONS>, dim3((unsigned)cdiv(a.R, 4)), dim3(256), 0, st, a);

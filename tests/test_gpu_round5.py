@@ -267,31 +267,3 @@ def test_conv_weight_gradient_bf16x6_matches_float64(device, cin, cout, hin, G, 
         _lib.check(lib.marl_tune(b"wgrad3", 1))
     assert errs[1][0] <= 2e-6 and errs[0][0] <= 2e-6 and errs[1][1] <= 2e-6, errs
     assert errs[1][0] <= 1.5 * errs[0][0] + 2e-7, errs
-
-
-def test_first_layer_gradient_inside_the_dz0_launch_matches_the_reference(device):
-    """opt-in form (knob dgrad_w0 = 1, measured slower and therefore off by default): layer 0's weight / bias gradient
-    formed inside the launch that produces dZ_0 - the default path's gradients (2e-5 of scale) on G2 (MNIST, 1 input channel) and
-    G4 (RESISC45, 3 channels), everything else bit-identical to the default path"""
-    from marlclassification_amd import engine as E
-
-    for tag in ("g2_mnist_c1", "g4_resisc_b2"):
-        g = Golden(tag)
-        res = {}
-        try:
-            for mode in (0, 1):
-                E.tune("dgrad_w0", mode)
-                eng = E.HipEngine(model_spec(g.cfg), device)
-                eng.configure(g.na, g.nb, g.ns, g.img.shape[1:])
-                eng.pack({k: v.to(device) for k, v in g.params.items()})
-                res[mode] = _run(eng, g, device, g.nb)[1]
-        finally:
-            E.tune("dgrad_w0", 0)
-        conv0 = [k for k in res[0] if "map_obs" in k and "layers.0." in k]
-        assert len(conv0) == 2, conv0
-        for k in res[0]:
-            if k in conv0:  # (another summation order: compared with the default path, itself checked against the reference)
-                ref = res[0][k]
-                assert (res[1][k].double() - ref.double()).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9, k
-            else:
-                assert th.equal(res[0][k], res[1][k]), k
