@@ -2907,7 +2907,6 @@ static size_t cnn_wgrad_plan(CnnWgradArgs& a) {
 
 int cnn_wgrad_supported(const CnnWgradArgs& a0) {
     if (getenv("MARL_CNN_FUSED") && getenv("MARL_CNN_FUSED")[0] == '0') return 0;
-    if (getenv("MARL_CNN_WGRAD") && getenv("MARL_CNN_WGRAD")[0] == '0') return 0;
     CnnWgradArgs a = a0;
     return cnn_wgrad_plan(a) > 0;  // (the bf16x6 form covers a subset of these shapes)
 }

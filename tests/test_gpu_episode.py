@@ -245,7 +245,6 @@ def test_other_baseline_configs_match_oracle(device, tag):
 
 
 @pytest.mark.parametrize("env", [{"MARL_CNN_FUSED": "0", "MARL_PANELS": "0"},
-                                 {"MARL_CNN_WGRAD": "0"},
                                  {"MARL_PANEL_CHAIN": "0", "MARL_RED_DEFER": "0"}])
 def test_alternative_kernel_paths_in_subprocess(device, env):
     """The unfused CNN / LayerNorm-GEMM fallbacks (used for shapes outside the fused kernels'
