@@ -2771,7 +2771,7 @@ static size_t cnn_wgrad3_plan(CnnWgradArgs& a) {
     a.dhin = make_fdiv(a.hin);
     a.dcin = make_fdiv(a.cin);
     if (best_nkt == 0) return 0;
-    const int lds_cap_kb = tune_get("wgrad3_lds_kb", best_nkt == 9 ? 150 : 76);
+    const int lds_cap_kb = best_nkt == 9 ? 150 : 76;
     int rb_cap = 16;
     if (rb_cap < 1) rb_cap = 1;
     for (int v = 0; v < 2; ++v) {
