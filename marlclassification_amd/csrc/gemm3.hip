@@ -1612,6 +1612,10 @@ int launch_gemm_lstm3(const G3Batch& batch, hipStream_t st, int variant) {
         rc = launch_g3p_variant<256, 128, 4, 2, 4, true>(batch, max_m, max_n, st);
     else if (variant == 6)  // ... or four waves of 128 x 64 (one per SIMD)
         rc = launch_g3p_variant<256, 128, 2, 2, 4, true>(batch, max_m, max_n, st);
+#ifdef MARL_G3_ABLATE
+    else if (variant == 7)  // (ring depth probe, tools/lstm_p_depth.py: three stages instead of four)
+        rc = launch_g3p_variant<256, 128, 2, 2, 3, true>(batch, max_m, max_n, st);
+#endif
     else
         rc = launch_g3_variant<128, 128, 4, 1, 3, true>(batch, max_m, max_n, st);
     prof_after(0, st);
