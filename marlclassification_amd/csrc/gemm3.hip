@@ -1566,10 +1566,6 @@ int launch_gemm_nt3(const G3Batch& batch, hipStream_t st, int variant) {
         rc = launch_g3p_variant<256, 256, 2, 4, 3, false>(batch, max_m, max_n, st);
     else if (variant == 22)  // phase-pipelined, 256 x 128 / 8 waves
         rc = launch_g3p_variant<256, 128, 4, 2, 4, false>(batch, max_m, max_n, st);
-    else if (variant == 23)  // phase-pipelined, 128 x 64 / 4 waves (two workgroups per CU)
-        rc = launch_g3p_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);
-    else if (variant == 24)  // phase-pipelined, 128 x 128 / 4 waves
-        rc = launch_g3p_variant<128, 128, 2, 2, 3, false>(batch, max_m, max_n, st);
 
     else
         rc = launch_g3_variant<128, 64, 2, 2, 4, false>(batch, max_m, max_n, st);

@@ -1,5 +1,6 @@
 """Round 6: the in-loop backward batch (4 products, M = 4096, K = 1024, n = 256 / 256 / 112 / 112) on the tile plans:
-7 = 64 x 64 (shipped), 3 = 128 x 64, 2 = 128 x 128, 23 / 24 = phase-pipelined 128 x 64 / 128 x 128."""
+7 = 64 x 64 (shipped), 3 = 128 x 64, 2 = 128 x 128; 23 / 24 = phase-pipelined 128 x 64 / 128 x 128 (round-6 experiment: needs the two
+launch_g3p_variant lines of commit "memory-side counters ..." in launch_gemm_nt3; measured 41.2 / 40.6 us against 39.0 for 64 x 64)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch as th
