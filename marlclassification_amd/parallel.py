@@ -14,6 +14,7 @@ all-reduce, C ABI phases 1/2 of marl_a2c_loss_fwd_bwd).
 
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch as th
@@ -79,6 +80,8 @@ class BucketedGradAllReduce(GradAllReduce):
         heads = sorted(off for name, off in offsets.items() if name.startswith(HEAD_PREFIXES))
         others = [off for name, off in offsets.items() if not name.startswith(HEAD_PREFIXES)]
         self.split = heads[0] if heads and (not others or max(others) < heads[0]) else None
+        if os.environ.get("MARL_GRAD_BUCKETS") == "1":  # (escape hatch: the single all-reduce of rounds 1-5)
+            self.split = None
         self.numel = numel
         self._event = None
         self._side = None
